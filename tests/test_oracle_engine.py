@@ -1,0 +1,173 @@
+"""Oracle engine tests (CPU): the C restatement of ccoherent::threadf against the committed
+golden vectors (tests/golden, produced by the fp64 model) and against known-answer cases.
+Tolerances: lags exact; phase <= 1e-5 rad vs fp64; int8 matrix equal except
++-1 LSB at rint boundaries; mag relative 1e-5."""
+import os
+
+import numpy as np
+import pytest
+
+
+def _load(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name + ".npz"))
+
+
+def _check_block(out, g, t, nrows):
+    assert np.array_equal(out["lag"], g["lag"][t])
+    assert np.allclose(out["mag"], g["mag"][t], rtol=1e-5)
+    assert np.allclose(out["frac"], g["frac"][t], atol=2e-3)
+    ph, gp = out["phasor"][1:], g["phasor"][t][1:]
+    assert np.abs(np.angle(ph * np.conj(gp))).max() <= 1e-5
+    assert np.allclose(np.abs(ph), np.abs(gp), rtol=1e-5)
+    diff = out["matrix"].astype(np.int16) - g["matrix"][t].astype(np.int16)
+    assert np.abs(diff).max() <= 1
+    assert np.count_nonzero(diff) <= 1e-3 * diff.size
+    assert np.array_equal(out["matrix"][0], g["rows"][t][0])   # raw ref row, src/cpacketizer.cc:151
+
+
+@pytest.mark.parametrize("name", ["cfg1_faithful", "cfg1_digital", "small_digital"])
+def test_engine_matches_golden(oracle, golden_dir, name):
+    g = _load(golden_dir, name)
+    nblocks, nrows, B = g["rows"].shape
+    e = oracle.Engine(nrows, B, int(g["mode"]))
+    for t in range(nblocks):
+        _check_block(e.block(g["rows"][t], seq=t), g, t, nrows)
+    # the golden lags are the injected delays (sign convention: s[n] = r[n-d]  =>  lag = +d)
+    assert np.array_equal(g["lag"][-1][1:], g["d"])
+
+
+def test_golden_regenerates_from_seed(synth, golden_dir):
+    # the fixture inputs are exactly what the seeded generator produces (no hidden state)
+    g = _load(golden_dir, "small_digital")
+    nblocks, nrows, B = g["rows"].shape
+    p = synth.RowParams(nrows - 1, B // 2, int(g["seed"]), dmax=100)
+    for t in range(nblocks):
+        rows, _ = synth.make_block(nrows - 1, B // 2, int(g["seed"]), t, params=p)
+        assert np.array_equal(rows, g["rows"][t])
+
+
+def _delayed_rows(L, delays, phis, seed=5, sigma=30.0):
+    rng = np.random.default_rng(seed)
+    pad = L
+    r_ext = rng.standard_normal(L + 2 * pad) + 1j * rng.standard_normal(L + 2 * pad)
+    rows = np.zeros((1 + len(delays), 2 * L), dtype=np.int8)
+
+    def q(x):
+        out = np.empty(2 * L, dtype=np.int8)
+        out[0::2] = np.clip(np.rint(x.real), -128, 127)
+        out[1::2] = np.clip(np.rint(x.imag), -128, 127)
+        return out
+
+    n = np.arange(L)
+    rows[0] = q(sigma * r_ext[pad:pad + L])
+    for k, (d, phi) in enumerate(zip(delays, phis)):
+        rows[1 + k] = q(sigma * r_ext[n - d + pad] * np.exp(1j * phi))
+    return rows
+
+
+def test_known_delays_give_idx_L_plus_d(oracle):
+    # SURVEY 8c known answers: d in {0, +-1, +-7, +-1000, -L/2+1}  ->  idx = L + d, lag = d
+    L = 4096
+    delays = [0, 1, -1, 7, -7, 1000, -1000, -L // 2 + 1]
+    rows = _delayed_rows(L, delays, [0.0] * len(delays))
+    e = oracle.Engine(1 + len(delays), 2 * L, oracle.FAITHFUL)
+    out = e.block(rows)
+    assert list(out["lag"][1:]) == delays
+    assert np.all(np.abs(out["frac"][1:]) < 0.05)
+
+
+def test_pure_rotation_gives_conjugate_phasor(oracle):
+    # a10: corr = sum s conj(r) = |.| e^{j phi}; p_raw = conj(corr)/|corr| = e^{-j phi};
+    # first block EMA with p_prev = 1: p = 0.5 e^{-j phi} + 0.5  (src/csdrdevice.cc:63-67)
+    L = 2048
+    phis = [0.3, -1.2, 2.9, -3.0]
+    rows = _delayed_rows(L, [0] * 4, phis)
+    e = oracle.Engine(5, 2 * L, oracle.FAITHFUL)
+    out = e.block(rows)
+    for k, phi in enumerate(phis):
+        expect = 0.5 * np.exp(-1j * phi) + 0.5
+        assert abs(out["phasor"][1 + k] - expect) < 2e-3
+    # EMA converges to the unit phasor over blocks; refnoise off freezes it (src/ccoherent.cc:271)
+    for _ in range(20):
+        out = e.block(rows)
+    for k, phi in enumerate(phis):
+        assert abs(out["phasor"][1 + k] - np.exp(-1j * phi)) < 2e-3
+    frozen = out["phasor"].copy()
+    out = e.block(_delayed_rows(L, [0] * 4, [1.0] * 4), refnoise_enabled=False)
+    assert np.array_equal(out["phasor"], frozen)
+
+
+def test_digital_mode_centres_the_correlation_peak(oracle, model):
+    # mirrors matlabclient/seqnum_and_correlation.m:27-43: after alignment every row's xcorr
+    # against the ref row peaks at the centre (lag 0) with the phase removed
+    L = 2048
+    delays, phis = [13, -200, 511], [0.7, -2.0, 3.0]
+    rows = _delayed_rows(L, delays, phis)
+    e = oracle.Engine(4, 2 * L, oracle.DIGITAL)
+    for _ in range(12):
+        out = e.block(rows)
+    ref = model.to_complex(out["matrix"][0])
+    for k in range(3):
+        y = model.to_complex(out["matrix"][1 + k])
+        lag, mag, frac, _ = model.xcorr_lag(y, ref)
+        assert lag == 0
+        corr = np.sum(y * np.conj(ref))
+        assert abs(np.angle(corr)) < 2e-2
+
+
+def test_lag_mask_and_nfft_cap(oracle):
+    L = 1024
+    delays = [5, -9, 30, 77, -100, 3, 4, 8, 15]
+    rows = _delayed_rows(L, delays, [0.0] * len(delays))
+    n = 1 + len(delays)
+    e = oracle.Engine(n, 2 * L, oracle.FAITHFUL)
+    mask = np.zeros(n, dtype=np.uint8)
+    mask[[2, 4]] = 1
+    out = e.block(rows, lag_mask=mask)
+    assert out["lag"][2] == delays[1] and out["lag"][4] == delays[3]
+    assert out["lag"][1] == 0 and out["lag"][3] == 0          # not requested: previous value (0)
+    # reference cap: nfft = 8 -> ref + 7 signal rows per block (src/ccoherent.cc:124, src/main.cc:165)
+    e8 = oracle.Engine(n, 2 * L, oracle.FAITHFUL, nfft_cap=8)
+    out = e8.block(rows)
+    assert list(out["lag"][1:8]) == delays[:7] and list(out["lag"][8:]) == [0, 0]
+
+
+def test_zero_row_policy_and_saturation(oracle):
+    # all-zero row: |corr| = 0 -> estimate skipped, phasor stays at its previous value (defined
+    # policy; the reference would go NaN for ever, src/csdrdevice.cc:63-67)
+    L = 512
+    rows = _delayed_rows(L, [0, 0], [0.5, 0.5])
+    rows[2] = 0
+    e = oracle.Engine(3, 2 * L, oracle.FAITHFUL)
+    out = e.block(rows)
+    assert out["phasor"][2] == 1.0 + 0j and np.all(out["matrix"][2] == 0)
+    assert not np.any(np.isnan(out["phasor"].view(np.float32)))
+    # saturating input: -128 * (1/127) * 127 rounds back to -128, and rotation gain is clamped
+    rows[1, 0::2], rows[1, 1::2] = -128, 127
+    rows[0] = rows[1]
+    e.reset()
+    out = e.block(rows)
+    assert out["matrix"][1].min() == -128 and out["matrix"][1].max() == 127
+
+
+def test_packet_layout(oracle):
+    # hdr0 {seq, N, L, 0} + readcnt[N] + int8[N][B]  (include/cpacketizer.h:32-37,
+    # src/cpacketizer.cc:137-172; parser matlabclient/zmqsdr.c:118-144)
+    L = 256
+    rows = _delayed_rows(L, [1, 2], [0.0, 0.0])
+    e = oracle.Engine(3, 2 * L, oracle.FAITHFUL)
+    out = e.block(rows, readcnt=[7, 8, 9], seq=41)
+    pkt = out["packet"]
+    assert pkt.size == 16 + 4 * 3 + 3 * 2 * L
+    hdr = pkt[:16].view(np.uint32)
+    assert list(hdr) == [41, 3, L, 0]
+    assert list(pkt[16:28].view(np.uint32)) == [7, 8, 9]
+    assert np.array_equal(pkt[28:28 + 2 * L], rows[0])
+
+
+def test_multithreaded_driver_is_identical(oracle, synth):
+    rows, p = synth.make_block(9, 1024, 77, 0, dmax=100)
+    a = oracle.Engine(10, 2048, oracle.DIGITAL).block(rows, nthreads=1)
+    b = oracle.Engine(10, 2048, oracle.DIGITAL).block(rows, nthreads=4)
+    for k in ("lag", "mag", "phasor", "packet"):
+        assert np.array_equal(a[k], b[k])
