@@ -1,0 +1,277 @@
+"""ctypes view of the C ABI in include/crsdr.h (libcrsdr.so).
+
+This is plumbing for tests and bench.py; the product boundary is the C ABI itself.  There is
+no fallback: if the HIP extension is missing or no device is present, calls raise.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "libcrsdr.so")
+ROOT = os.path.dirname(_HERE)
+
+MODE_FAITHFUL, MODE_DIGITAL = 0, 1
+MEM_HOST, MEM_DEVICE = 0, 1
+REFNOISE_ENABLED, OFFSET_BINARY, INPUT_READY, NO_LAG = 1, 2, 4, 8
+
+# every symbol include/crsdr.h declares (tests check the .so exports all of them)
+ABI_SYMBOLS = [
+    "crsdr_abi_version", "crsdr_last_error", "crsdr_device_count",
+    "crsdr_convtosigned", "crsdr_convtofloat", "crsdr_scalarmul", "crsdr_convto8bit",
+    "crsdr_conj_dotproduct", "crsdr_magsquared", "crsdr_conjugatemul", "crsdr_indexofmax", "crsdr_fft",
+    "crsdr_plan_create", "crsdr_plan_destroy", "crsdr_plan_reset", "crsdr_plan_set_stream",
+    "crsdr_plan_submit", "crsdr_plan_fetch", "crsdr_plan_sync", "crsdr_plan_packet_bytes",
+    "crsdr_plan_matrix_offset", "crsdr_plan_device_buffers", "crsdr_plan_bind_packet",
+    "crsdr_plan_last_elapsed_ms", "crsdr_plan_enable_profiling", "crsdr_plan_kernel_times",
+]
+KERNEL_REF_SPECTRUM, KERNEL_XCORR_LAG, KERNEL_ALIGN_QUANT = 0, 1, 2
+
+
+class CrsdrError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"crsdr error {code}: {msg}")
+        self.code = code
+
+
+def build(force: bool = False) -> str:
+    """Compile libcrsdr.so for gfx950 with hipcc (cross-compiles without a GPU)."""
+    csrc = os.path.join(_HERE, "csrc")
+    deps = [os.path.join(csrc, f) for f in os.listdir(csrc)] + [os.path.join(ROOT, "include", "crsdr.h")]
+    stale = force or not os.path.exists(_SO) or any(os.path.getmtime(d) > os.path.getmtime(_SO) for d in deps)
+    if stale:
+        subprocess.run(["make", "-C", csrc], check=True)
+    return _SO
+
+
+class PlanDesc(C.Structure):
+    _fields_ = [("nrows", C.c_int32), ("blocksize", C.c_int32), ("mode", C.c_int32), ("device", C.c_int32),
+                ("row_begin", C.c_int32), ("row_count", C.c_int32), ("reserved", C.c_uint32 * 2)]
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(_SO):
+        raise FileNotFoundError(f"{_SO} is missing: run __graft_entry__.build() (hipcc) first; there is no CPU fallback")
+    L = C.CDLL(_SO)
+    f32p, i8p, u8p, u32p, i32p, vp = (C.POINTER(C.c_float), C.POINTER(C.c_int8), C.POINTER(C.c_uint8),
+                                      C.POINTER(C.c_uint32), C.POINTER(C.c_int32), C.c_void_p)
+    L.crsdr_abi_version.restype = C.c_int
+    L.crsdr_last_error.restype = C.c_char_p
+    L.crsdr_device_count.argtypes = [C.POINTER(C.c_int)]
+    L.crsdr_convtosigned.argtypes = [u8p, u8p, C.c_int]
+    L.crsdr_convtofloat.argtypes = [f32p, i8p, C.c_int]
+    L.crsdr_scalarmul.argtypes = [f32p, f32p, C.c_float, C.c_float, C.c_int]
+    L.crsdr_convto8bit.argtypes = [i8p, f32p, C.c_int]
+    L.crsdr_conj_dotproduct.argtypes = [f32p, f32p, f32p, C.c_int]
+    L.crsdr_magsquared.argtypes = [f32p, f32p, C.c_int]
+    L.crsdr_conjugatemul.argtypes = [f32p, f32p, f32p, C.c_int]
+    L.crsdr_indexofmax.argtypes = [u32p, f32p, C.c_int]
+    L.crsdr_fft.argtypes = [f32p, f32p, C.c_int, C.c_int, C.c_int]
+    L.crsdr_plan_create.argtypes = [C.POINTER(vp), C.POINTER(PlanDesc)]
+    L.crsdr_plan_destroy.argtypes = [vp]
+    L.crsdr_plan_reset.argtypes = [vp]
+    L.crsdr_plan_set_stream.argtypes = [vp, vp]
+    L.crsdr_plan_submit.argtypes = [vp, vp, C.c_int, u32p, u8p, C.c_uint32, C.c_uint32]
+    L.crsdr_plan_fetch.argtypes = [vp, i32p, f32p, f32p, f32p, i8p]
+    L.crsdr_plan_sync.argtypes = [vp]
+    L.crsdr_plan_packet_bytes.argtypes = [vp]
+    L.crsdr_plan_packet_bytes.restype = C.c_size_t
+    L.crsdr_plan_matrix_offset.argtypes = [vp]
+    L.crsdr_plan_matrix_offset.restype = C.c_size_t
+    L.crsdr_plan_device_buffers.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]
+    L.crsdr_plan_bind_packet.argtypes = [vp, vp]
+    L.crsdr_plan_last_elapsed_ms.argtypes = [vp, C.POINTER(C.c_float)]
+    L.crsdr_plan_enable_profiling.argtypes = [vp, C.c_int]
+    L.crsdr_plan_kernel_times.argtypes = [vp, C.c_int, f32p, C.c_int, C.POINTER(C.c_int)]
+    _lib = L
+    return L
+
+
+def _check(rc):
+    if rc != 0:
+        raise CrsdrError(rc, lib().crsdr_last_error().decode(errors="replace"))
+
+
+def _p(a, ty):
+    return a.ctypes.data_as(C.POINTER(ty)) if a is not None else None
+
+
+def _c64(a):
+    a = np.ascontiguousarray(a, dtype=np.complex64)
+    return a, a.view(np.float32)
+
+
+def device_count() -> int:
+    n = C.c_int(0)
+    rc = lib().crsdr_device_count(C.byref(n))
+    return n.value if rc == 0 else 0
+
+
+# ---- per-op wrappers (class cdsp), numpy host arrays in / out ----------------------------------
+
+def convtosigned(u8):
+    u8 = np.ascontiguousarray(u8, dtype=np.uint8)
+    out = np.empty_like(u8)
+    _check(lib().crsdr_convtosigned(_p(u8, C.c_uint8), _p(out, C.c_uint8), u8.size))
+    return out.view(np.int8)
+
+
+def convtofloat(i8):
+    i8 = np.ascontiguousarray(i8, dtype=np.int8)
+    out = np.empty(i8.size, dtype=np.float32)
+    _check(lib().crsdr_convtofloat(_p(out, C.c_float), _p(i8, C.c_int8), i8.size))
+    return out.view(np.complex64)
+
+
+def scalarmul(x, s):
+    x, xf = _c64(x)
+    out = np.empty_like(x)
+    s = np.complex64(s)
+    _check(lib().crsdr_scalarmul(_p(out.view(np.float32), C.c_float), _p(xf, C.c_float), float(s.real), float(s.imag), x.size))
+    return out
+
+
+def convto8bit(x):
+    x, xf = _c64(x)
+    out = np.empty(2 * x.size, dtype=np.int8)
+    _check(lib().crsdr_convto8bit(_p(out, C.c_int8), _p(xf, C.c_float), x.size))
+    return out
+
+
+def conj_dotproduct(a, b):
+    a, af = _c64(a)
+    b, bf = _c64(b)
+    res = np.zeros(2, dtype=np.float32)
+    _check(lib().crsdr_conj_dotproduct(_p(res, C.c_float), _p(af, C.c_float), _p(bf, C.c_float), a.size))
+    return np.complex64(res[0] + 1j * res[1])
+
+
+def magsquared(x):
+    x, xf = _c64(x)
+    out = np.empty(x.size, dtype=np.float32)
+    _check(lib().crsdr_magsquared(_p(out, C.c_float), _p(xf, C.c_float), x.size))
+    return out
+
+
+def conjugatemul(a, b):
+    a, af = _c64(a)
+    b, bf = _c64(b)
+    out = np.empty_like(a)
+    _check(lib().crsdr_conjugatemul(_p(out.view(np.float32), C.c_float), _p(af, C.c_float), _p(bf, C.c_float), a.size))
+    return out
+
+
+def indexofmax(m):
+    m = np.ascontiguousarray(m, dtype=np.float32)
+    idx = C.c_uint32(0)
+    _check(lib().crsdr_indexofmax(C.byref(idx), _p(m, C.c_float), m.size))
+    return int(idx.value)
+
+
+def fft(x, sign=-1):
+    x, xf = _c64(x)
+    n = x.shape[-1]
+    out = np.empty_like(x)
+    _check(lib().crsdr_fft(_p(out.view(np.float32), C.c_float), _p(xf, C.c_float), n, sign, x.size // n))
+    return out
+
+
+# ---- batched plan ---------------------------------------------------------------------------------
+
+class Plan:
+    """crsdr_plan: ccoherent + per-row csdrdevice DSP members + cpacketize::write on one GPU."""
+
+    def __init__(self, nrows, blocksize, mode=MODE_FAITHFUL, device=0, row_begin=0, row_count=0):
+        self.nrows, self.B, self.mode = nrows, blocksize, mode
+        d = PlanDesc(nrows, blocksize, mode, device, row_begin, row_count)
+        h = C.c_void_p()
+        _check(lib().crsdr_plan_create(C.byref(h), C.byref(d)))
+        self._h = h
+        self._keep = []
+        self.packet_bytes = int(lib().crsdr_plan_packet_bytes(h))
+        self.matrix_offset = int(lib().crsdr_plan_matrix_offset(h))
+
+    def set_stream(self, hip_stream: int | None):
+        _check(lib().crsdr_plan_set_stream(self._h, C.c_void_p(hip_stream or 0)))
+
+    def submit(self, rows, readcnt=None, lag_mask=None, seq=0, flags=REFNOISE_ENABLED):
+        """rows: numpy int8/uint8 [nrows][B] (host) or an int device pointer."""
+        rc_arr = None if readcnt is None else np.ascontiguousarray(readcnt, dtype=np.uint32)
+        mk = None if lag_mask is None else np.ascontiguousarray(lag_mask, dtype=np.uint8)
+        if isinstance(rows, (int, np.integer)):
+            ptr, kind = C.c_void_p(int(rows)), MEM_DEVICE
+        else:
+            if rows.dtype not in (np.int8, np.uint8):
+                raise TypeError("rows must be int8 (or offset-binary uint8)")
+            keep = np.ascontiguousarray(rows)
+            assert keep.shape == (self.nrows, self.B)
+            self._keep.append(keep)          # stays alive until the next fetch()/sync()
+            ptr, kind = C.c_void_p(keep.ctypes.data), MEM_HOST
+        _check(lib().crsdr_plan_submit(self._h, ptr, kind, _p(rc_arr, C.c_uint32), _p(mk, C.c_uint8), int(seq), int(flags)))
+
+    def fetch(self, want_packet=True):
+        n = self.nrows
+        lag = np.zeros(n, dtype=np.int32)
+        mag = np.zeros(n, dtype=np.float32)
+        frac = np.zeros(n, dtype=np.float32)
+        ph = np.zeros(2 * n, dtype=np.float32)
+        pkt = np.zeros(self.packet_bytes, dtype=np.int8) if want_packet else None
+        _check(lib().crsdr_plan_fetch(self._h, _p(lag, C.c_int32), _p(mag, C.c_float), _p(frac, C.c_float),
+                                      _p(ph, C.c_float), _p(pkt, C.c_int8)))
+        self._keep.clear()
+        return dict(lag=lag, mag=mag, frac=frac, phasor=ph.view(np.complex64), packet=pkt,
+                    matrix=None if pkt is None else pkt[self.matrix_offset:].reshape(self.nrows, self.B))
+
+    def block(self, rows, **kw):
+        self.submit(rows, **kw)
+        return self.fetch()
+
+    def sync(self):
+        _check(lib().crsdr_plan_sync(self._h))
+        self._keep.clear()
+
+    def reset(self):
+        _check(lib().crsdr_plan_reset(self._h))
+
+    def device_buffers(self):
+        ptrs = [C.c_void_p() for _ in range(5)]
+        _check(lib().crsdr_plan_device_buffers(self._h, *[C.byref(p) for p in ptrs]))
+        return dict(zip(("packet", "lag", "mag", "frac", "phasor"), [p.value for p in ptrs]))
+
+    def bind_packet(self, device_ptr: int | None):
+        _check(lib().crsdr_plan_bind_packet(self._h, C.c_void_p(device_ptr or 0)))
+
+    def last_elapsed_ms(self) -> float:
+        ms = C.c_float(0)
+        _check(lib().crsdr_plan_last_elapsed_ms(self._h, C.byref(ms)))
+        return float(ms.value)
+
+    def enable_profiling(self, slots: int):
+        _check(lib().crsdr_plan_enable_profiling(self._h, int(slots)))
+
+    def kernel_times_ms(self, which: int, capacity: int = 4096) -> np.ndarray:
+        out = np.zeros(capacity, dtype=np.float32)
+        n = C.c_int(0)
+        _check(lib().crsdr_plan_kernel_times(self._h, int(which), _p(out, C.c_float), capacity, C.byref(n)))
+        return out[: n.value].copy()
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().crsdr_plan_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,0 +1,665 @@
+// crsdr.hip -- C ABI (include/crsdr.h) over the gfx950 kernels in kernels.hpp.
+// Host side is plain C++: plan = device buffers + twiddle table + two HIP streams + events.
+// No torch types, no CPU fallback: every compute entry point needs a HIP device.
+#include "../../include/crsdr.h"
+#include "kernels.hpp"
+
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <new>
+#include <vector>
+
+using namespace crsdr;
+
+// ---- error plumbing ---------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+
+static int fail(int code, const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                               \
+    do {                                                                                            \
+        hipError_t e_ = (expr);                                                                     \
+        if (e_ != hipSuccess)                                                                       \
+            return fail(e_ == hipErrorOutOfMemory ? CRSDR_ENOMEM                                    \
+                        : (e_ == hipErrorNoDevice || e_ == hipErrorInvalidDevice) ? CRSDR_ENODEV    \
+                                                                                  : CRSDR_EHIP,     \
+                        "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+
+extern "C" int crsdr_abi_version(void) { return CRSDR_ABI_VERSION; }
+extern "C" const char *crsdr_last_error(void) { return g_err; }
+
+extern "C" int crsdr_device_count(int *count)
+{
+    if (!count) return fail(CRSDR_EINVAL, "count is NULL");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) { *count = 0; return fail(CRSDR_ENODEV, "hipGetDeviceCount: %s", hipGetErrorString(e)); }
+    *count = n;
+    return CRSDR_OK;
+}
+
+static int require_device()
+{
+    int n = 0;
+    int rc = crsdr_device_count(&n);
+    if (rc) return rc;
+    if (n < 1) return fail(CRSDR_ENODEV, "no HIP device: libcrsdr has no CPU fallback");
+    return CRSDR_OK;
+}
+
+static int ilog2_exact(int n)
+{
+    if (n < 1 || (n & (n - 1))) return -1;
+    int l = 0;
+    while ((1 << l) < n) ++l;
+    return l;
+}
+
+// forward twiddle table W_n^k = (cos, -sin)(2 pi k / n), generated in double, rounded once
+static int make_twiddles(int n, float2 **d_tw)
+{
+    std::vector<float2> h((size_t)n);
+    for (int k = 0; k < n; ++k) {
+        double a = 2.0 * M_PI * (double)k / (double)n;
+        h[k] = make_float2((float)std::cos(a), (float)(-std::sin(a)));
+    }
+    HIP_TRY(hipMalloc((void **)d_tw, sizeof(float2) * (size_t)n));
+    HIP_TRY(hipMemcpy(*d_tw, h.data(), sizeof(float2) * (size_t)n, hipMemcpyHostToDevice));
+    return CRSDR_OK;
+}
+
+constexpr int kMinLog2 = 4, kMaxLog2 = 14; // LDS-resident transform sizes: 16 .. 16384 points
+
+template <int LOG2N>
+static constexpr size_t fft_lds_bytes() { return sizeof(float2) * ((size_t)1 << LOG2N) + 256; }
+
+// ---- kernel launchers, dispatched on log2(B) ------------------------------------------------------
+template <int LOG2N>
+static hipError_t launch_ref_spectrum(hipStream_t s, const int8_t *ref_row, const float2 *tw, float2 *refspec, uint32_t xor80)
+{
+    auto kern = k_ref_spectrum<LOG2N>;
+    constexpr size_t lds = fft_lds_bytes<LOG2N>();
+    hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(kern, dim3(1), dim3(FftGeom<LOG2N>::THREADS), lds, s, ref_row, tw, refspec, xor80);
+    return hipGetLastError();
+}
+
+template <int LOG2N>
+static hipError_t launch_xcorr_lag(hipStream_t s, int nblocks, const int8_t *rows, const float2 *tw, const float2 *refspec,
+                                   const uint8_t *mask, int row_begin, uint32_t xor80, int32_t *lag, float *mag, float *frac)
+{
+    auto kern = k_xcorr_lag<LOG2N>;
+    constexpr size_t lds = fft_lds_bytes<LOG2N>();
+    hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(kern, dim3(nblocks), dim3(FftGeom<LOG2N>::THREADS), lds, s, rows, tw, refspec, mask, row_begin,
+                       xor80, lag, mag, frac);
+    return hipGetLastError();
+}
+
+template <int LOG2N, int DIR>
+static hipError_t launch_op_fft(hipStream_t s, int howmany, float2 *out, const float2 *in, const float2 *tw)
+{
+    auto kern = k_op_fft<LOG2N, DIR>;
+    constexpr size_t lds = fft_lds_bytes<LOG2N>();
+    hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(kern, dim3(howmany), dim3(FftGeom<LOG2N>::THREADS), lds, s, out, in, tw);
+    return hipGetLastError();
+}
+
+#define CRSDR_DISPATCH_LOG2(l2, CALL)                                                   \
+    [&]() -> hipError_t {                                                               \
+        switch (l2) {                                                                   \
+        case 4: { constexpr int LG = 4; return CALL; }                                  \
+        case 5: { constexpr int LG = 5; return CALL; }                                  \
+        case 6: { constexpr int LG = 6; return CALL; }                                  \
+        case 7: { constexpr int LG = 7; return CALL; }                                  \
+        case 8: { constexpr int LG = 8; return CALL; }                                  \
+        case 9: { constexpr int LG = 9; return CALL; }                                  \
+        case 10: { constexpr int LG = 10; return CALL; }                                \
+        case 11: { constexpr int LG = 11; return CALL; }                                \
+        case 12: { constexpr int LG = 12; return CALL; }                                \
+        case 13: { constexpr int LG = 13; return CALL; }                                \
+        case 14: { constexpr int LG = 14; return CALL; }                                \
+        default: return hipErrorInvalidValue;                                           \
+        }                                                                               \
+    }()
+
+// ================================================================================================
+// (i) per-op entry points (class cdsp).  Host pointers; staged through grow-only device buffers.
+// ================================================================================================
+namespace {
+struct OpCtx {
+    std::mutex mu;
+    void *buf[3] = {nullptr, nullptr, nullptr};
+    size_t cap[3] = {0, 0, 0};
+    float2 *tw[kMaxLog2 + 1] = {};
+    int tw_dev[kMaxLog2 + 1] = {};
+    int dev = -1;
+};
+OpCtx g_op;
+
+int op_reserve(int slot, size_t bytes)
+{
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    if (g_op.dev != dev) {
+        for (int i = 0; i < 3; ++i) { if (g_op.buf[i]) (void)hipFree(g_op.buf[i]); g_op.buf[i] = nullptr; g_op.cap[i] = 0; }
+        for (int i = 0; i <= kMaxLog2; ++i) { if (g_op.tw[i]) (void)hipFree(g_op.tw[i]); g_op.tw[i] = nullptr; }
+        g_op.dev = dev;
+    }
+    if (g_op.cap[slot] >= bytes) return CRSDR_OK;
+    if (g_op.buf[slot]) (void)hipFree(g_op.buf[slot]);
+    g_op.buf[slot] = nullptr; g_op.cap[slot] = 0;
+    size_t want = bytes < 4096 ? 4096 : bytes;
+    HIP_TRY(hipMalloc(&g_op.buf[slot], want));
+    g_op.cap[slot] = want;
+    return CRSDR_OK;
+}
+
+inline dim3 grid1d(size_t n, int bs = 256) { return dim3((unsigned)((n + bs - 1) / bs)); }
+} // namespace
+
+#define OP_PROLOGUE(cond, msg)                                \
+    if (!(cond)) return fail(CRSDR_EINVAL, msg);              \
+    { int rc_ = require_device(); if (rc_) return rc_; }      \
+    std::lock_guard<std::mutex> lock_(g_op.mu)
+
+#define OP_RESERVE(slot, bytes) { int rc_ = op_reserve(slot, bytes); if (rc_) return rc_; }
+
+extern "C" int crsdr_convtosigned(const uint8_t *in, uint8_t *out, int n)
+{
+    OP_PROLOGUE(in && out && n > 0 && (n % 8) == 0, "convtosigned: need in, out, n > 0, n % 8 == 0");
+    OP_RESERVE(0, n); OP_RESERVE(1, n);
+    HIP_TRY(hipMemcpy(g_op.buf[0], in, n, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_op_convtosigned, grid1d(n / 4), dim3(256), 0, 0, (const uint32_t *)g_op.buf[0], (uint32_t *)g_op.buf[1], n / 4);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpy(out, g_op.buf[1], n, hipMemcpyDeviceToHost));
+    return CRSDR_OK;
+}
+
+extern "C" int crsdr_convtofloat(float *out, const int8_t *s8bit, int n)
+{
+    OP_PROLOGUE(out && s8bit && n > 0, "convtofloat: need out, s8bit, n > 0");
+    OP_RESERVE(0, n); OP_RESERVE(1, sizeof(float) * (size_t)n);
+    HIP_TRY(hipMemcpy(g_op.buf[0], s8bit, n, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_op_convtofloat, grid1d(n), dim3(256), 0, 0, (float *)g_op.buf[1], (const int8_t *)g_op.buf[0], n);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpy(out, g_op.buf[1], sizeof(float) * (size_t)n, hipMemcpyDeviceToHost));
+    return CRSDR_OK;
+}
+
+extern "C" int crsdr_scalarmul(float *out, const float *in, float sre, float sim, int n)
+{
+    OP_PROLOGUE(out && in && n > 0, "scalarmul: need out, in, n > 0");
+    const size_t bytes = sizeof(float2) * (size_t)n;
+    OP_RESERVE(0, bytes); OP_RESERVE(1, bytes);
+    HIP_TRY(hipMemcpy(g_op.buf[0], in, bytes, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_op_scalarmul, grid1d(n), dim3(256), 0, 0, (float2 *)g_op.buf[1], (const float2 *)g_op.buf[0], make_float2(sre, sim), n);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpy(out, g_op.buf[1], bytes, hipMemcpyDeviceToHost));
+    return CRSDR_OK;
+}
+
+extern "C" int crsdr_convto8bit(int8_t *out, const float *in, int n)
+{
+    OP_PROLOGUE(out && in && n > 0, "convto8bit: need out, in, n > 0");
+    const size_t nf = 2 * (size_t)n; // the reference doubles n internally (src/cdsp.cc:52)
+    OP_RESERVE(0, sizeof(float) * nf); OP_RESERVE(1, nf);
+    HIP_TRY(hipMemcpy(g_op.buf[0], in, sizeof(float) * nf, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_op_convto8bit, grid1d(nf), dim3(256), 0, 0, (int8_t *)g_op.buf[1], (const float *)g_op.buf[0], (int)nf);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpy(out, g_op.buf[1], nf, hipMemcpyDeviceToHost));
+    return CRSDR_OK;
+}
+
+extern "C" int crsdr_conj_dotproduct(float *res, const float *a, const float *b, int n)
+{
+    OP_PROLOGUE(res && a && b && n > 0, "conj_dotproduct: need res, a, b, n > 0");
+    const size_t bytes = sizeof(float2) * (size_t)n;
+    OP_RESERVE(0, bytes); OP_RESERVE(1, bytes); OP_RESERVE(2, 16);
+    HIP_TRY(hipMemcpy(g_op.buf[0], a, bytes, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(g_op.buf[1], b, bytes, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_op_conj_dot, dim3(1), dim3(1024), 0, 0, (float *)g_op.buf[2], (const float2 *)g_op.buf[0], (const float2 *)g_op.buf[1], n);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpy(res, g_op.buf[2], 2 * sizeof(float), hipMemcpyDeviceToHost));
+    return CRSDR_OK;
+}
+
+extern "C" int crsdr_magsquared(float *out, const float *in, int n)
+{
+    OP_PROLOGUE(out && in && n > 0, "magsquared: need out, in, n > 0");
+    OP_RESERVE(0, sizeof(float2) * (size_t)n); OP_RESERVE(1, sizeof(float) * (size_t)n);
+    HIP_TRY(hipMemcpy(g_op.buf[0], in, sizeof(float2) * (size_t)n, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_op_magsquared, grid1d(n), dim3(256), 0, 0, (float *)g_op.buf[1], (const float2 *)g_op.buf[0], n);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpy(out, g_op.buf[1], sizeof(float) * (size_t)n, hipMemcpyDeviceToHost));
+    return CRSDR_OK;
+}
+
+extern "C" int crsdr_conjugatemul(float *out, const float *in1, const float *in2, int n)
+{
+    OP_PROLOGUE(out && in1 && in2 && n > 0, "conjugatemul: need out, in1, in2, n > 0");
+    const size_t bytes = sizeof(float2) * (size_t)n;
+    OP_RESERVE(0, bytes); OP_RESERVE(1, bytes); OP_RESERVE(2, bytes);
+    HIP_TRY(hipMemcpy(g_op.buf[0], in1, bytes, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(g_op.buf[1], in2, bytes, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_op_conjugatemul, grid1d(n), dim3(256), 0, 0, (float2 *)g_op.buf[2], (const float2 *)g_op.buf[0], (const float2 *)g_op.buf[1], n);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpy(out, g_op.buf[2], bytes, hipMemcpyDeviceToHost));
+    return CRSDR_OK;
+}
+
+extern "C" int crsdr_indexofmax(uint32_t *index, const float *in, int n)
+{
+    OP_PROLOGUE(index && in && n > 0, "indexofmax: need index, in, n > 0");
+    OP_RESERVE(0, sizeof(float) * (size_t)n); OP_RESERVE(2, 16);
+    HIP_TRY(hipMemcpy(g_op.buf[0], in, sizeof(float) * (size_t)n, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_op_indexofmax, dim3(1), dim3(1024), 0, 0, (uint32_t *)g_op.buf[2], (const float *)g_op.buf[0], n);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpy(index, g_op.buf[2], sizeof(uint32_t), hipMemcpyDeviceToHost));
+    return CRSDR_OK;
+}
+
+extern "C" int crsdr_fft(float *out, const float *in, int n, int sign, int howmany)
+{
+    OP_PROLOGUE(out && in && howmany > 0 && (sign == 1 || sign == -1), "fft: need out, in, howmany > 0, sign = +-1");
+    const int l2 = ilog2_exact(n);
+    if (l2 < kMinLog2 || l2 > kMaxLog2)
+        return fail(CRSDR_EINVAL, "fft: n = %d unsupported (power of two in [16, 16384])", n);
+    const size_t bytes = sizeof(float2) * (size_t)n * (size_t)howmany;
+    OP_RESERVE(0, bytes); OP_RESERVE(1, bytes);
+    if (!g_op.tw[l2]) { int rc = make_twiddles(n, &g_op.tw[l2]); if (rc) return rc; }
+    HIP_TRY(hipMemcpy(g_op.buf[0], in, bytes, hipMemcpyHostToDevice));
+    const float2 *tw = g_op.tw[l2];
+    hipError_t e = (sign < 0)
+        ? CRSDR_DISPATCH_LOG2(l2, (launch_op_fft<LG, -1>(0, howmany, (float2 *)g_op.buf[1], (const float2 *)g_op.buf[0], tw)))
+        : CRSDR_DISPATCH_LOG2(l2, (launch_op_fft<LG, +1>(0, howmany, (float2 *)g_op.buf[1], (const float2 *)g_op.buf[0], tw)));
+    HIP_TRY(e);
+    HIP_TRY(hipMemcpy(out, g_op.buf[1], bytes, hipMemcpyDeviceToHost));
+    return CRSDR_OK;
+}
+
+// ================================================================================================
+// (ii) batched plan
+// ================================================================================================
+constexpr int kStageSlots = 4;
+
+struct crsdr_plan {
+    int nrows = 0, B = 0, L = 0, log2n = 0, mode = 0, device = 0, row_begin = 1, row_count = 0;
+    size_t packet_bytes = 0, matrix_off = 0;
+    hipStream_t own_stream = nullptr, stream = nullptr, aux = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_ref[2] = {nullptr, nullptr}, ev_k1done[2] = {nullptr, nullptr};
+    hipEvent_t ev_aux_done = nullptr, ev_start = nullptr, ev_stop = nullptr;
+    bool k1done_valid[2] = {false, false};
+    int slot = 0;
+    float2 *d_tw = nullptr, *d_refspec[2] = {nullptr, nullptr};
+    int8_t *d_rows = nullptr;          // staging for host input [nrows][B]
+    uint8_t *d_packet_alloc = nullptr; // own packet allocation (front padding for alignment)
+    int8_t *d_packet_own = nullptr, *d_packet = nullptr;
+    uint32_t *d_readcnt = nullptr;
+    uint8_t *d_mask = nullptr;
+    int32_t *d_lag = nullptr;
+    float *d_mag = nullptr, *d_frac = nullptr;
+    float2 *d_phasor = nullptr;
+    // pinned staging ring for the small per-block host arrays
+    uint32_t *h_readcnt = nullptr;
+    uint8_t *h_mask = nullptr;
+    hipEvent_t ev_stage[kStageSlots] = {};
+    bool stage_valid[kStageSlots] = {};
+    int stage_slot = 0;
+    bool submitted = false;
+    // optional per-kernel event pairs (crsdr_plan_enable_profiling)
+    int prof_slots = 0;
+    long prof_count = 0;                 // submits recorded since enable
+    std::vector<hipEvent_t> prof_ev;     // [slot][kernel][begin,end]
+    std::vector<unsigned char> prof_has; // [slot][kernel]
+};
+
+static hipEvent_t *prof_pair(crsdr_plan *p, int which)
+{
+    if (!p->prof_slots) return nullptr;
+    const int slot = (int)(p->prof_count % p->prof_slots);
+    p->prof_has[(size_t)slot * 3 + which] = 1;
+    return &p->prof_ev[((size_t)slot * 3 + which) * 2];
+}
+
+static int plan_init_state(crsdr_plan *p)
+{
+    std::vector<float2> ph((size_t)p->nrows, make_float2(1.0f, 0.0f)); // src/csdrdevice.cc:39-40
+    ph[0] = make_float2(0.0f, 0.0f);                                   // pcorrection[0] is never written
+    HIP_TRY(hipMemcpy(p->d_phasor, ph.data(), sizeof(float2) * ph.size(), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemset(p->d_lag, 0, sizeof(int32_t) * (size_t)p->nrows));
+    HIP_TRY(hipMemset(p->d_mag, 0, sizeof(float) * (size_t)p->nrows));
+    HIP_TRY(hipMemset(p->d_frac, 0, sizeof(float) * (size_t)p->nrows));
+    return CRSDR_OK;
+}
+
+static int plan_alloc(crsdr_plan *p)
+{
+    HIP_TRY(hipSetDevice(p->device));
+    HIP_TRY(hipStreamCreateWithFlags(&p->own_stream, hipStreamNonBlocking));
+    HIP_TRY(hipStreamCreateWithFlags(&p->aux, hipStreamNonBlocking));
+    p->stream = p->own_stream;
+    hipEvent_t *evs[] = {&p->ev_fork, &p->ev_ref[0], &p->ev_ref[1], &p->ev_k1done[0], &p->ev_k1done[1], &p->ev_aux_done};
+    for (auto e : evs) HIP_TRY(hipEventCreateWithFlags(e, hipEventDisableTiming));
+    for (int i = 0; i < kStageSlots; ++i) HIP_TRY(hipEventCreateWithFlags(&p->ev_stage[i], hipEventDisableTiming));
+    HIP_TRY(hipEventCreate(&p->ev_start));
+    HIP_TRY(hipEventCreate(&p->ev_stop));
+    { int rc = make_twiddles(p->B, &p->d_tw); if (rc) return rc; }
+    const size_t rowbytes = (size_t)p->nrows * (size_t)p->B;
+    for (int i = 0; i < 2; ++i) HIP_TRY(hipMalloc((void **)&p->d_refspec[i], sizeof(float2) * (size_t)p->B));
+    HIP_TRY(hipMalloc((void **)&p->d_rows, rowbytes));
+    // own packet: pad the front so that the matrix (at +16+4N) starts 256-byte aligned
+    const size_t pad = (256 - (p->matrix_off % 256)) % 256;
+    HIP_TRY(hipMalloc((void **)&p->d_packet_alloc, pad + p->packet_bytes + 256));
+    HIP_TRY(hipMemset(p->d_packet_alloc, 0, pad + p->packet_bytes + 256));
+    p->d_packet_own = reinterpret_cast<int8_t *>(p->d_packet_alloc + pad);
+    p->d_packet = p->d_packet_own;
+    HIP_TRY(hipMalloc((void **)&p->d_readcnt, sizeof(uint32_t) * (size_t)p->nrows));
+    HIP_TRY(hipMalloc((void **)&p->d_mask, (size_t)p->nrows));
+    HIP_TRY(hipMalloc((void **)&p->d_lag, sizeof(int32_t) * (size_t)p->nrows));
+    HIP_TRY(hipMalloc((void **)&p->d_mag, sizeof(float) * (size_t)p->nrows));
+    HIP_TRY(hipMalloc((void **)&p->d_frac, sizeof(float) * (size_t)p->nrows));
+    HIP_TRY(hipMalloc((void **)&p->d_phasor, sizeof(float2) * (size_t)p->nrows));
+    HIP_TRY(hipHostMalloc((void **)&p->h_readcnt, sizeof(uint32_t) * (size_t)p->nrows * kStageSlots, hipHostMallocDefault));
+    HIP_TRY(hipHostMalloc((void **)&p->h_mask, (size_t)p->nrows * kStageSlots, hipHostMallocDefault));
+    return plan_init_state(p);
+}
+
+static void plan_free(crsdr_plan *p)
+{
+    if (!p) return;
+    (void)hipSetDevice(p->device);
+    if (p->own_stream) (void)hipStreamSynchronize(p->own_stream);
+    if (p->aux) (void)hipStreamSynchronize(p->aux);
+    void *bufs[] = {p->d_tw, p->d_refspec[0], p->d_refspec[1], p->d_rows, p->d_packet_alloc, p->d_readcnt, p->d_mask,
+                    p->d_lag, p->d_mag, p->d_frac, p->d_phasor};
+    for (void *b : bufs) if (b) (void)hipFree(b);
+    if (p->h_readcnt) (void)hipHostFree(p->h_readcnt);
+    if (p->h_mask) (void)hipHostFree(p->h_mask);
+    hipEvent_t evs[] = {p->ev_fork, p->ev_ref[0], p->ev_ref[1], p->ev_k1done[0], p->ev_k1done[1], p->ev_aux_done, p->ev_start, p->ev_stop};
+    for (hipEvent_t e : evs) if (e) (void)hipEventDestroy(e);
+    for (int i = 0; i < kStageSlots; ++i) if (p->ev_stage[i]) (void)hipEventDestroy(p->ev_stage[i]);
+    for (hipEvent_t e : p->prof_ev) if (e) (void)hipEventDestroy(e);
+    if (p->own_stream) (void)hipStreamDestroy(p->own_stream);
+    if (p->aux) (void)hipStreamDestroy(p->aux);
+    delete p;
+}
+
+extern "C" int crsdr_plan_create(crsdr_plan **plan, const crsdr_plan_desc *desc)
+{
+    if (!plan || !desc) return fail(CRSDR_EINVAL, "plan_create: NULL argument");
+    *plan = nullptr;
+    const int l2 = ilog2_exact(desc->blocksize);
+    if (desc->nrows < 2) return fail(CRSDR_EINVAL, "plan_create: nrows = %d (need the ref row and >= 1 signal row)", desc->nrows);
+    if (l2 < kMinLog2 || l2 > kMaxLog2)
+        return fail(CRSDR_EINVAL, "plan_create: blocksize = %d unsupported (power of two in [16, 16384])", desc->blocksize);
+    if (desc->mode != CRSDR_MODE_FAITHFUL && desc->mode != CRSDR_MODE_DIGITAL)
+        return fail(CRSDR_EINVAL, "plan_create: mode = %d", desc->mode);
+    const int rb = desc->row_begin ? desc->row_begin : 1;
+    const int rc_rows = desc->row_count ? desc->row_count : desc->nrows - rb;
+    if (rb < 1 || rc_rows < 1 || rb + rc_rows > desc->nrows)
+        return fail(CRSDR_EINVAL, "plan_create: slab [%d,%d) outside signal rows [1,%d)", rb, rb + rc_rows, desc->nrows);
+    { int rc = require_device(); if (rc) return rc; }
+    int ndev = 0;
+    (void)crsdr_device_count(&ndev);
+    if (desc->device < 0 || desc->device >= ndev) return fail(CRSDR_ENODEV, "plan_create: device %d of %d", desc->device, ndev);
+
+    crsdr_plan *p = new (std::nothrow) crsdr_plan();
+    if (!p) return fail(CRSDR_ENOMEM, "plan_create: out of host memory");
+    p->nrows = desc->nrows; p->B = desc->blocksize; p->L = p->B / 2; p->log2n = l2; p->mode = desc->mode;
+    p->device = desc->device; p->row_begin = rb; p->row_count = rc_rows;
+    p->matrix_off = 16 + 4 * (size_t)p->nrows;
+    p->packet_bytes = p->matrix_off + (size_t)p->nrows * (size_t)p->B;
+    int rc = plan_alloc(p);
+    if (rc) { plan_free(p); return rc; }
+    *plan = p;
+    return CRSDR_OK;
+}
+
+extern "C" int crsdr_plan_destroy(crsdr_plan *plan)
+{
+    if (!plan) return fail(CRSDR_EINVAL, "plan_destroy: NULL plan");
+    plan_free(plan);
+    return CRSDR_OK;
+}
+
+extern "C" int crsdr_plan_sync(crsdr_plan *p)
+{
+    if (!p) return fail(CRSDR_EINVAL, "plan_sync: NULL plan");
+    HIP_TRY(hipSetDevice(p->device));
+    HIP_TRY(hipStreamSynchronize(p->stream));
+    HIP_TRY(hipStreamSynchronize(p->aux));
+    return CRSDR_OK;
+}
+
+extern "C" int crsdr_plan_reset(crsdr_plan *p)
+{
+    if (!p) return fail(CRSDR_EINVAL, "plan_reset: NULL plan");
+    int rc = crsdr_plan_sync(p);
+    if (rc) return rc;
+    p->submitted = false;
+    return plan_init_state(p);
+}
+
+extern "C" int crsdr_plan_set_stream(crsdr_plan *p, void *hip_stream)
+{
+    if (!p) return fail(CRSDR_EINVAL, "plan_set_stream: NULL plan");
+    int rc = crsdr_plan_sync(p);
+    if (rc) return rc;
+    p->stream = hip_stream ? (hipStream_t)hip_stream : p->own_stream;
+    return CRSDR_OK;
+}
+
+extern "C" size_t crsdr_plan_packet_bytes(const crsdr_plan *p) { return p ? p->packet_bytes : 0; }
+extern "C" size_t crsdr_plan_matrix_offset(const crsdr_plan *p) { return p ? p->matrix_off : 0; }
+
+extern "C" int crsdr_plan_device_buffers(crsdr_plan *p, void **packet, void **lag, void **mag, void **frac, void **phasor)
+{
+    if (!p) return fail(CRSDR_EINVAL, "plan_device_buffers: NULL plan");
+    if (packet) *packet = p->d_packet;
+    if (lag) *lag = p->d_lag;
+    if (mag) *mag = p->d_mag;
+    if (frac) *frac = p->d_frac;
+    if (phasor) *phasor = p->d_phasor;
+    return CRSDR_OK;
+}
+
+extern "C" int crsdr_plan_bind_packet(crsdr_plan *p, void *device_packet)
+{
+    if (!p) return fail(CRSDR_EINVAL, "plan_bind_packet: NULL plan");
+    if (device_packet && (((uintptr_t)device_packet + p->matrix_off) % 4) != 0)
+        return fail(CRSDR_EINVAL, "plan_bind_packet: matrix start must be 4-byte aligned");
+    p->d_packet = device_packet ? (int8_t *)device_packet : p->d_packet_own;
+    return CRSDR_OK;
+}
+
+extern "C" int crsdr_plan_submit(crsdr_plan *p, const void *rows, int mem_kind, const uint32_t *readcnt,
+                                 const uint8_t *lag_mask, uint32_t seq, uint32_t flags)
+{
+    if (!p || !rows) return fail(CRSDR_EINVAL, "plan_submit: NULL plan or rows");
+    if (mem_kind != CRSDR_MEM_HOST && mem_kind != CRSDR_MEM_DEVICE) return fail(CRSDR_EINVAL, "plan_submit: mem_kind = %d", mem_kind);
+    HIP_TRY(hipSetDevice(p->device));
+    hipStream_t S = p->stream, A = p->aux;
+    const size_t B = (size_t)p->B;
+    const uint32_t xor80 = (flags & CRSDR_OFFSET_BINARY) ? 0x80808080u : 0u;
+
+    const int8_t *d_in = (const int8_t *)rows;
+    bool input_ready = (flags & CRSDR_INPUT_READY) && mem_kind == CRSDR_MEM_DEVICE;
+    if (mem_kind == CRSDR_MEM_HOST) {
+        // reference row + this plan's slab only (cbuffer hand-off, src/crtlsdr.cc:173-203)
+        HIP_TRY(hipMemcpyAsync(p->d_rows, rows, B, hipMemcpyHostToDevice, S));
+        HIP_TRY(hipMemcpyAsync(p->d_rows + B * (size_t)p->row_begin, (const int8_t *)rows + B * (size_t)p->row_begin,
+                               B * (size_t)p->row_count, hipMemcpyHostToDevice, S));
+        d_in = p->d_rows;
+    }
+
+    // small per-block host arrays through the pinned ring
+    const uint32_t *d_readcnt = nullptr;
+    const uint8_t *d_mask = nullptr;
+    bool any_lag = !(flags & CRSDR_NO_LAG);
+    if (readcnt || lag_mask) {
+        const int ss = p->stage_slot;
+        p->stage_slot = (ss + 1) % kStageSlots;
+        if (p->stage_valid[ss]) HIP_TRY(hipEventSynchronize(p->ev_stage[ss]));
+        if (readcnt) {
+            uint32_t *h = p->h_readcnt + (size_t)ss * p->nrows;
+            memcpy(h, readcnt, sizeof(uint32_t) * (size_t)p->nrows);
+            HIP_TRY(hipMemcpyAsync(p->d_readcnt, h, sizeof(uint32_t) * (size_t)p->nrows, hipMemcpyHostToDevice, S));
+            d_readcnt = p->d_readcnt;
+        }
+        if (lag_mask) {
+            uint8_t *h = p->h_mask + (size_t)ss * p->nrows;
+            memcpy(h, lag_mask, (size_t)p->nrows);
+            bool any = false;
+            for (int r = p->row_begin; r < p->row_begin + p->row_count; ++r) any |= (h[r] != 0);
+            any_lag = any_lag && any;
+            HIP_TRY(hipMemcpyAsync(p->d_mask, h, (size_t)p->nrows, hipMemcpyHostToDevice, S));
+            d_mask = p->d_mask;
+        }
+        HIP_TRY(hipEventRecord(p->ev_stage[ss], S));
+        p->stage_valid[ss] = true;
+    }
+
+    if (p->prof_slots) {
+        const int ps = (int)(p->prof_count % p->prof_slots);
+        for (int k = 0; k < 3; ++k) p->prof_has[(size_t)ps * 3 + k] = 0;
+    }
+    HIP_TRY(hipEventRecord(p->ev_start, S));
+    HIP_TRY(hipEventRecord(p->ev_fork, S)); // everything enqueued on S so far (input copies, caller's work)
+
+    AlignArgs aa;
+    aa.rows = d_in; aa.packet = p->d_packet; aa.readcnt = d_readcnt; aa.lag = p->d_lag; aa.phasecorr = p->d_phasor;
+    aa.nrows = p->nrows; aa.B = p->B; aa.row_begin = p->row_begin;
+    aa.digital = (p->mode == CRSDR_MODE_DIGITAL); aa.refnoise = (flags & CRSDR_REFNOISE_ENABLED) ? 1 : 0;
+    aa.seq = seq; aa.xor80 = xor80;
+    const dim3 k2grid((unsigned)(1 + p->row_count)), k2block(kAlignThreads);
+
+    if (any_lag) {
+        const int slot = (p->slot ^= 1);
+        // K0 on the aux stream: may overlap the previous block's K1 when the input is resident
+        if (!input_ready) HIP_TRY(hipStreamWaitEvent(A, p->ev_fork, 0));
+        if (p->k1done_valid[slot]) HIP_TRY(hipStreamWaitEvent(A, p->ev_k1done[slot], 0)); // refspec[slot] free again
+        hipEvent_t *pe0 = prof_pair(p, CRSDR_KERNEL_REF_SPECTRUM);
+        if (pe0) HIP_TRY(hipEventRecord(pe0[0], A));
+        HIP_TRY(CRSDR_DISPATCH_LOG2(p->log2n, (launch_ref_spectrum<LG>(A, d_in, p->d_tw, p->d_refspec[slot], xor80))));
+        if (pe0) HIP_TRY(hipEventRecord(pe0[1], A));
+        HIP_TRY(hipEventRecord(p->ev_ref[slot], A));
+        if (!aa.digital) {
+            // faithful: the phase path does not depend on this block's lags (src/ccoherent.cc:271-278
+            // run before computelag :284) -> K2 on the aux stream, concurrent with K1
+            if (input_ready) HIP_TRY(hipStreamWaitEvent(A, p->ev_fork, 0)); // packet buffer ordering
+            hipEvent_t *pe2 = prof_pair(p, CRSDR_KERNEL_ALIGN_QUANT);
+            if (pe2) HIP_TRY(hipEventRecord(pe2[0], A));
+            hipLaunchKernelGGL(k_align_quant, k2grid, k2block, 0, A, aa);
+            HIP_TRY(hipGetLastError());
+            if (pe2) HIP_TRY(hipEventRecord(pe2[1], A));
+            HIP_TRY(hipEventRecord(p->ev_aux_done, A));
+        }
+        HIP_TRY(hipStreamWaitEvent(S, p->ev_ref[slot], 0));
+        hipEvent_t *pe1 = prof_pair(p, CRSDR_KERNEL_XCORR_LAG);
+        if (pe1) HIP_TRY(hipEventRecord(pe1[0], S));
+        HIP_TRY(CRSDR_DISPATCH_LOG2(p->log2n, (launch_xcorr_lag<LG>(S, p->row_count, d_in, p->d_tw, p->d_refspec[slot], d_mask,
+                                                                    p->row_begin, xor80, p->d_lag, p->d_mag, p->d_frac))));
+        if (pe1) HIP_TRY(hipEventRecord(pe1[1], S));
+        HIP_TRY(hipEventRecord(p->ev_k1done[slot], S));
+        p->k1done_valid[slot] = true;
+        if (aa.digital) {
+            hipEvent_t *pe2 = prof_pair(p, CRSDR_KERNEL_ALIGN_QUANT);
+            if (pe2) HIP_TRY(hipEventRecord(pe2[0], S));
+            hipLaunchKernelGGL(k_align_quant, k2grid, k2block, 0, S, aa);
+            HIP_TRY(hipGetLastError());
+            if (pe2) HIP_TRY(hipEventRecord(pe2[1], S));
+        } else {
+            HIP_TRY(hipStreamWaitEvent(S, p->ev_aux_done, 0)); // join
+        }
+    } else {
+        // "locked" steady state: no row requests a lag -> phase path only (src/ccoherent.cc:284 skipped)
+        hipEvent_t *pe2 = prof_pair(p, CRSDR_KERNEL_ALIGN_QUANT);
+        if (pe2) HIP_TRY(hipEventRecord(pe2[0], S));
+        hipLaunchKernelGGL(k_align_quant, k2grid, k2block, 0, S, aa);
+        HIP_TRY(hipGetLastError());
+        if (pe2) HIP_TRY(hipEventRecord(pe2[1], S));
+    }
+    HIP_TRY(hipEventRecord(p->ev_stop, S));
+    p->submitted = true;
+    if (p->prof_slots) p->prof_count++;
+    return CRSDR_OK;
+}
+
+extern "C" int crsdr_plan_fetch(crsdr_plan *p, int32_t *lag, float *mag, float *frac, float *phasor, int8_t *packet)
+{
+    if (!p) return fail(CRSDR_EINVAL, "plan_fetch: NULL plan");
+    if (!p->submitted) return fail(CRSDR_ESTATE, "plan_fetch: nothing submitted");
+    HIP_TRY(hipSetDevice(p->device));
+    HIP_TRY(hipStreamSynchronize(p->stream));
+    const size_t n = (size_t)p->nrows;
+    if (lag) HIP_TRY(hipMemcpy(lag, p->d_lag, sizeof(int32_t) * n, hipMemcpyDeviceToHost));
+    if (mag) HIP_TRY(hipMemcpy(mag, p->d_mag, sizeof(float) * n, hipMemcpyDeviceToHost));
+    if (frac) HIP_TRY(hipMemcpy(frac, p->d_frac, sizeof(float) * n, hipMemcpyDeviceToHost));
+    if (phasor) HIP_TRY(hipMemcpy(phasor, p->d_phasor, sizeof(float2) * n, hipMemcpyDeviceToHost));
+    if (packet) HIP_TRY(hipMemcpy(packet, p->d_packet, p->packet_bytes, hipMemcpyDeviceToHost));
+    return CRSDR_OK;
+}
+
+extern "C" int crsdr_plan_last_elapsed_ms(crsdr_plan *p, float *ms)
+{
+    if (!p || !ms) return fail(CRSDR_EINVAL, "plan_last_elapsed_ms: NULL argument");
+    if (!p->submitted) return fail(CRSDR_ESTATE, "plan_last_elapsed_ms: nothing submitted");
+    HIP_TRY(hipSetDevice(p->device));
+    HIP_TRY(hipEventSynchronize(p->ev_stop));
+    HIP_TRY(hipEventElapsedTime(ms, p->ev_start, p->ev_stop));
+    return CRSDR_OK;
+}
+
+extern "C" int crsdr_plan_enable_profiling(crsdr_plan *p, int slots)
+{
+    if (!p || slots < 0 || slots > 4096) return fail(CRSDR_EINVAL, "plan_enable_profiling: bad argument");
+    int rc = crsdr_plan_sync(p);
+    if (rc) return rc;
+    for (hipEvent_t e : p->prof_ev) if (e) (void)hipEventDestroy(e);
+    p->prof_ev.clear(); p->prof_has.clear();
+    p->prof_slots = 0; p->prof_count = 0;
+    if (slots == 0) return CRSDR_OK;
+    p->prof_ev.assign((size_t)slots * 6, nullptr);
+    p->prof_has.assign((size_t)slots * 3, 0);
+    for (auto &e : p->prof_ev) HIP_TRY(hipEventCreate(&e));
+    p->prof_slots = slots;
+    return CRSDR_OK;
+}
+
+extern "C" int crsdr_plan_kernel_times(crsdr_plan *p, int which, float *ms, int capacity, int *count)
+{
+    if (!p || !ms || !count || which < 0 || which > 2 || capacity < 0) return fail(CRSDR_EINVAL, "plan_kernel_times: bad argument");
+    *count = 0;
+    if (!p->prof_slots) return fail(CRSDR_ESTATE, "plan_kernel_times: profiling not enabled");
+    int rc = crsdr_plan_sync(p);
+    if (rc) return rc;
+    const long n = p->prof_count < p->prof_slots ? p->prof_count : p->prof_slots;
+    const long first = p->prof_count - n;
+    for (long i = first; i < p->prof_count && *count < capacity; ++i) {
+        const int slot = (int)(i % p->prof_slots);
+        if (!p->prof_has[(size_t)slot * 3 + which]) continue;
+        hipEvent_t *pe = &p->prof_ev[((size_t)slot * 3 + which) * 2];
+        float t = 0.f;
+        HIP_TRY(hipEventElapsedTime(&t, pe[0], pe[1]));
+        ms[(*count)++] = t;
+    }
+    return CRSDR_OK;
+}

@@ -1,0 +1,414 @@
+// kernels.hpp -- gfx950 kernels of the coherent-alignment path (included by crsdr.hip only).
+//
+//   k_ref_spectrum  K0  int8 ref row -> pad at [L,2L) -> B-point DIF FFT -> conj -> HBM
+//                       (crefsdr::convtofloat src/crtlsdr.cc:215-218 + sfft slot 0 of
+//                        src/ccoherent.cc:174)
+//   k_xcorr_lag     K1  one workgroup per signal row, everything LDS/register resident:
+//                       int8 -> pad at [0,L) -> DIF FFT -> x conj(ref spectrum) -> DIT inverse
+//                       FFT -> |.|^2 -> workgroup argmax (first maximum) -> lag, mag, frac
+//                       (src/crtlsdr.cc:205-207, src/ccoherent.cc:123-142,174-234)
+//   k_align_quant   K2  one workgroup per row: exact integer conjugate dot product against
+//                       the ref row -> unit phasor -> EMA -> rotate (+ integer shift in
+//                       digital mode) -> x127, saturate, round-half-even -> int8 row at its
+//                       packet offset (src/csdrdevice.cc:58-84, src/cpacketizer.cc:137-172)
+//   k_op_*              single-op kernels behind the per-op C ABI (class cdsp)
+#pragma once
+#include "fft_lds.hpp"
+#include <stdint.h>
+
+namespace crsdr {
+
+// ---- bit-parity arithmetic helpers (no FMA contraction: one rounding per op, oracle order) --
+
+// cdsp::convtofloat src/cdsp.cc:41-44: (float)x * (1.0f/127.0f)
+__device__ __forceinline__ float i8_to_f32(int x) { return __fmul_rn((float)x, 1.0f / 127.0f); }
+
+// cdsp::convto8bit src/cdsp.cc:51-54: r = x*127; clamp [-128,127]; rintf (half-even); NaN -> 0
+__device__ __forceinline__ int f32_to_i8(float x)
+{
+    float r = __fmul_rn(x, 127.0f);
+    if (r > 127.0f) return 127;
+    if (r < -128.0f) return -128;
+    if (r != r) return 0;
+    return (int)rintf(r);
+}
+
+// cdsp::scalarmul src/cdsp.cc:46-49: (ar*sr - ai*si) + j(ar*si + ai*sr), each op rounded once
+__device__ __forceinline__ float2 rot_rn(float2 a, float2 s)
+{
+    return make_float2(__fsub_rn(__fmul_rn(a.x, s.x), __fmul_rn(a.y, s.y)),
+                       __fadd_rn(__fmul_rn(a.x, s.y), __fmul_rn(a.y, s.x)));
+}
+
+__device__ __forceinline__ int sext8(uint32_t w, int byte) { return (int)(int8_t)((w >> (8 * byte)) & 0xFFu); }
+
+// ---- row load: int8 IQ row -> complex fp32 in LDS with the reference's zero-pad placement ----
+// signal rows: samples in A[0..L), zeros in A[L..2L)   (crtlsdr::convtofloat  src/crtlsdr.cc:205-207)
+// ref row    : zeros in A[0..L), samples in A[L..2L)   (crefsdr::convtofloat  src/crtlsdr.cc:215-218)
+// xor80: fuse cdsp::convtosigned (src/cdsp.cc:21-34) for offset-binary input.
+template <int LOG2N>
+__device__ __forceinline__ void load_row_to_lds(float2 *A, const int8_t *__restrict__ row, bool is_ref,
+                                                uint32_t xor80, int tid)
+{
+    using G = FftGeom<LOG2N>;
+    constexpr int N = G::N, L = N / 2;
+    const int data_off = is_ref ? L : 0, zero_off = is_ref ? 0 : L;
+    // one 32-bit word = two complex samples per lane per step: 256 B coalesced per wave from
+    // HBM, one conflict-free 16-byte LDS store per lane
+    const uint32_t *src = reinterpret_cast<const uint32_t *>(row);
+    float4 *dst = reinterpret_cast<float4 *>(A + data_off);
+    for (int c = tid; c < N / 4; c += G::THREADS) {
+        const uint32_t w = src[c] ^ xor80;
+        dst[c] = make_float4(i8_to_f32(sext8(w, 0)), i8_to_f32(sext8(w, 1)), i8_to_f32(sext8(w, 2)),
+                             i8_to_f32(sext8(w, 3)));
+    }
+    for (int n = tid; n < L; n += G::THREADS) A[zero_off + n] = make_float2(0.f, 0.f);
+}
+
+// ---- K0 ---------------------------------------------------------------------------------------
+template <int LOG2N>
+__global__ __launch_bounds__(FftGeom<LOG2N>::THREADS) void k_ref_spectrum(
+    const int8_t *__restrict__ ref_row, const float2 *__restrict__ tw, float2 *__restrict__ refspec, uint32_t xor80)
+{
+    using G = FftGeom<LOG2N>;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float2 *A = reinterpret_cast<float2 *>(smem);
+    const int tid = threadIdx.x;
+    load_row_to_lds<LOG2N>(A, ref_row, true, xor80, tid);
+    __syncthreads();
+    fft_dif_range<LOG2N, -1, 0, G::NPASS>(A, tw, tid);
+    // conj(X_ref) in DIF (digit-reversed) order: K1 multiplies element-wise in the same order
+    for (int j = tid; j < G::N; j += G::THREADS) {
+        float2 v = A[j];
+        refspec[j] = make_float2(v.x, -v.y);
+    }
+}
+
+// ---- K1 ---------------------------------------------------------------------------------------
+struct ArgMax {
+    float m;
+    int idx;
+};
+__device__ __forceinline__ void argmax_take(ArgMax &a, float m, int idx)
+{
+    // volk_32f_index_max_32u generic: first strict maximum -> ties resolve to the lowest index
+    if (m > a.m || (m == a.m && idx < a.idx)) { a.m = m; a.idx = idx; }
+}
+
+template <int LOG2N>
+__global__ __launch_bounds__(FftGeom<LOG2N>::THREADS) void k_xcorr_lag(
+    const int8_t *__restrict__ rows, const float2 *__restrict__ tw, const float2 *__restrict__ refspec,
+    const uint8_t *__restrict__ lag_mask, int row_begin, uint32_t xor80,
+    int32_t *__restrict__ lag, float *__restrict__ mag, float *__restrict__ frac)
+{
+    using G = FftGeom<LOG2N>;
+    constexpr int N = G::N, L = N / 2, NP = G::NPASS;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float2 *A = reinterpret_cast<float2 *>(smem);
+    ArgMax *wred = reinterpret_cast<ArgMax *>(smem + sizeof(float2) * N);
+    const int tid = threadIdx.x;
+    const int row = row_begin + blockIdx.x;
+    if (lag_mask && !lag_mask[row]) return; // not requested this block: lag/mag keep their value
+
+    load_row_to_lds<LOG2N>(A, rows + (size_t)row * N, false, xor80, tid);
+    __syncthreads();
+    // forward passes 0 .. NP-2 (each followed by a barrier)
+    fft_dif_range<LOG2N, -1, 0, NP - 1>(A, tw, tid);
+    // junction: last forward pass (stride 1, no twiddle) x conj(ref spectrum) -> first inverse
+    // pass, all in registers -- the two passes act on the same R contiguous points.
+    {
+        constexpr int LR = G::log2r(NP - 1), R = 1 << LR, NG = N / R;
+        static_assert(G::log2m(NP - 1) == 0, "last pass must have stride 1");
+        for (int g = tid; g < NG; g += G::THREADS) {
+            float2 v[R];
+#pragma unroll
+            for (int i = 0; i < R; ++i) v[i] = A[g * R + i];
+            dft<R, -1>(v);
+#pragma unroll
+            for (int i = 0; i < R; ++i) v[i] = cmul(v[i], refspec[g * R + i]); // sfft[k] * conj(sfft[0])
+            dft<R, +1>(v);
+#pragma unroll
+            for (int i = 0; i < R; ++i) A[g * R + i] = v[i];
+        }
+        __syncthreads();
+    }
+    // inverse passes NP-2 .. 1
+    fft_dit_range<LOG2N, +1, 1, NP - 1>(A, tw, tid);
+    // final inverse pass fused with |.|^2 and the per-thread argmax; |.|^2 is parked in A[].x
+    ArgMax best = {-1.0f, 0x7fffffff};
+    if constexpr (NP >= 2) {
+        constexpr int LR = G::log2r(0), R = 1 << LR, LM = G::log2m(0), NG = N / R;
+        for (int g = tid; g < NG; g += G::THREADS) {
+            const int n2 = g; // P = 0: single block, n2 = g
+            float2 v[R];
+#pragma unroll
+            for (int i = 0; i < R; ++i) v[i] = A[n2 + (i << LM)];
+#pragma unroll
+            for (int k = 1; k < R; ++k) v[k] = ctw<+1>(v[k], tw[n2 * k]);
+            dft<R, +1>(v);
+#pragma unroll
+            for (int i = 0; i < R; ++i) {
+                float m = fmaf(v[i].x, v[i].x, v[i].y * v[i].y);
+                A[n2 + (i << LM)].x = m;
+                argmax_take(best, m, n2 + (i << LM));
+            }
+        }
+    } else {
+        // single-pass transform (N == 16): the junction already produced natural order
+        for (int j = tid; j < N; j += G::THREADS) {
+            float2 v = A[j];
+            float m = fmaf(v.x, v.x, v.y * v.y);
+            A[j].x = m;
+            argmax_take(best, m, j);
+        }
+    }
+    // wavefront argmax (64 lanes), then across the workgroup's waves through LDS
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        float om = __shfl_xor(best.m, off, 64);
+        int oi = __shfl_xor(best.idx, off, 64);
+        argmax_take(best, om, oi);
+    }
+    const int wave = tid >> 6, lane = tid & 63;
+    if (lane == 0) wred[wave] = best;
+    __syncthreads();
+    if (tid == 0) {
+        constexpr int NW = G::THREADS / 64;
+        ArgMax b = wred[0];
+        for (int w = 1; w < NW; ++w) argmax_take(b, wred[w].m, wred[w].idx);
+        const int idx = ((unsigned)b.idx < (unsigned)N) ? b.idx : 0; // all-NaN row: defined as index 0
+        float D = 0.0f;
+        if (idx > 0 && idx < N - 1) {
+            float ym = A[idx - 1].x, yp = A[idx + 1].x;
+            float den = (ym - 2.0f * b.m) + yp;
+            if (den != 0.0f) D = (0.5f * (ym - yp)) / den;
+        }
+        lag[row] = idx - L;                       // src/ccoherent.cc:232
+        mag[row] = sqrtf(b.m / (float)L);         // src/ccoherent.cc:204
+        frac[row] = D;
+    }
+}
+
+// ---- K2 ---------------------------------------------------------------------------------------
+// grid.x = 1 + owned signal rows; block 0 copies the raw reference row (cpacketize::write(int8*)
+// src/cpacketizer.cc:137-156) and writes the header; block b >= 1 handles row row_begin + b - 1.
+struct AlignArgs {
+    const int8_t *rows;      // [nrows][B]
+    int8_t *packet;          // hdr + readcnt + matrix
+    const uint32_t *readcnt; // device [nrows] or nullptr (use seq)
+    const int32_t *lag;      // device [nrows]
+    float2 *phasecorr;       // device [nrows]  csdrdevice::phasecorr (== phasecorrprev after a block)
+    int nrows, B, row_begin;
+    int digital, refnoise;
+    uint32_t seq, xor80;
+};
+
+constexpr int kAlignThreads = 256;
+
+__global__ __launch_bounds__(kAlignThreads) void k_align_quant(AlignArgs a)
+{
+    __shared__ long long sred[2 * (kAlignThreads / 64)];
+    __shared__ float2 sp;
+    const int tid = threadIdx.x;
+    const int B = a.B, L = B >> 1;
+    const size_t moff = 16 + 4 * (size_t)a.nrows;
+    if (blockIdx.x == 0) {
+        // header hdr0{globalseqn,N,L,unused} src/cpacketizer.cc:112-116 and readcnt words :142,163
+        uint32_t *h = reinterpret_cast<uint32_t *>(a.packet);
+        if (tid == 0) { h[0] = a.seq; h[1] = (uint32_t)a.nrows; h[2] = (uint32_t)L; h[3] = 0u; }
+        for (int r = tid; r < a.nrows; r += kAlignThreads) h[4 + r] = a.readcnt ? a.readcnt[r] : a.seq;
+        const uint32_t *src = reinterpret_cast<const uint32_t *>(a.rows);
+        uint32_t *dst = reinterpret_cast<uint32_t *>(a.packet + moff);
+        for (int i = tid; i < B / 4; i += kAlignThreads) dst[i] = src[i] ^ a.xor80;
+        return;
+    }
+    const int row = a.row_begin + (int)blockIdx.x - 1;
+    const uint32_t *s32 = reinterpret_cast<const uint32_t *>(a.rows + (size_t)row * B);
+    const uint32_t *r32 = reinterpret_cast<const uint32_t *>(a.rows);
+    const int16_t *s16 = reinterpret_cast<const int16_t *>(a.rows + (size_t)row * B);
+    const int d = a.digital ? a.lag[row] : 0;
+    float2 p = a.phasecorr[row];
+
+    if (a.refnoise) {
+        // corr = sum_n y[n] conj(r[n]) with y[n] = s[n + d]; int8 products summed exactly in
+        // integers (|sum| <= 2^15 L): the fp32 value csdrdevice::est_phasecorrect
+        // (src/csdrdevice.cc:62) accumulates is a rounding of this, scaled by 1/127^2.
+        long long acc_re = 0, acc_im = 0;
+        if (d == 0) {
+            // two complex samples per 32-bit word: bytes [I0 Q0 I1 Q1]; int32 partials are safe
+            // (|term| <= 2^16 per word, <= 2^15 words per thread)
+            int re = 0, im = 0;
+            for (int i = tid; i < B / 4; i += kAlignThreads) {
+                uint32_t s = s32[i] ^ a.xor80, r = r32[i] ^ a.xor80;
+                uint32_t sw = ((s >> 8) & 0x00FF00FFu) | ((s << 8) & 0xFF00FF00u); // [Q0 I0 Q1 I1]
+                re = __builtin_amdgcn_sdot4((int)s, (int)r, re, false);               // I.I + Q.Q
+                im = __builtin_amdgcn_sdot4((int)sw, (int)(r & 0x00FF00FFu), im, false); // + Q.rI
+                im -= __builtin_amdgcn_sdot4((int)sw, (int)(r & 0xFF00FF00u), 0, false); // - I.rQ
+            }
+            acc_re += re; acc_im += im;
+        } else {
+            const int lo = d < 0 ? -d : 0, hi = d > 0 ? L - d : L; // overlap of shifted row and ref
+            const int16_t *r16 = reinterpret_cast<const int16_t *>(a.rows);
+            const uint32_t x16 = a.xor80 & 0xFFFFu;
+            for (int n = lo + tid; n < hi; n += kAlignThreads) {
+                uint32_t s = (uint16_t)s16[n + d] ^ x16, r = (uint16_t)r16[n] ^ x16;
+                int si = sext8(s, 0), sq = sext8(s, 1), ri = sext8(r, 0), rq = sext8(r, 1);
+                acc_re += si * ri + sq * rq;
+                acc_im += sq * ri - si * rq;
+            }
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            acc_re += __shfl_xor(acc_re, off, 64);
+            acc_im += __shfl_xor(acc_im, off, 64);
+        }
+        if ((tid & 63) == 0) { sred[2 * (tid >> 6)] = acc_re; sred[2 * (tid >> 6) + 1] = acc_im; }
+        __syncthreads();
+        if (tid == 0) {
+            long long sr = 0, si = 0;
+            for (int w = 0; w < kAlignThreads / 64; ++w) { sr += sred[2 * w]; si += sred[2 * w + 1]; }
+            if (sr != 0 || si != 0) {
+                // phasecorr = conj(corr)/|corr| (src/csdrdevice.cc:63), then the alpha = 0.5 EMA
+                // (:66-67).  |corr| == 0 holds the previous phasor (defined policy; the
+                // reference would go NaN for ever).
+                double cr = (double)sr, ci = (double)si;
+                double inv = 1.0 / sqrt(cr * cr + ci * ci);
+                float pr = (float)(cr * inv), pi = (float)(-ci * inv);
+                p = make_float2(__fadd_rn(__fmul_rn(0.5f, pr), __fmul_rn(0.5f, p.x)),
+                                __fadd_rn(__fmul_rn(0.5f, pi), __fmul_rn(0.5f, p.y)));
+                a.phasecorr[row] = p;
+            }
+            sp = p;
+        }
+        __syncthreads();
+        p = sp;
+    }
+
+    // csdrdevice::phasecorrect (src/csdrdevice.cc:80-84) + cpacketize::write(complex<float>*)
+    // (src/cpacketizer.cc:158-172): y * p, x127, saturate, round-half-even, int8 at row offset
+    int8_t *out = a.packet + moff + (size_t)row * B;
+    if (d == 0) {
+        uint32_t *o32 = reinterpret_cast<uint32_t *>(out);
+        for (int i = tid; i < B / 4; i += kAlignThreads) {
+            uint32_t s = s32[i] ^ a.xor80;
+            float2 y0 = rot_rn(make_float2(i8_to_f32(sext8(s, 0)), i8_to_f32(sext8(s, 1))), p);
+            float2 y1 = rot_rn(make_float2(i8_to_f32(sext8(s, 2)), i8_to_f32(sext8(s, 3))), p);
+            uint32_t w = (uint32_t)(f32_to_i8(y0.x) & 0xFF) | ((uint32_t)(f32_to_i8(y0.y) & 0xFF) << 8) |
+                         ((uint32_t)(f32_to_i8(y1.x) & 0xFF) << 16) | ((uint32_t)(f32_to_i8(y1.y) & 0xFF) << 24);
+            o32[i] = w;
+        }
+    } else {
+        uint16_t *o16 = reinterpret_cast<uint16_t *>(out);
+        const uint32_t x16 = a.xor80 & 0xFFFFu;
+        for (int n = tid; n < L; n += kAlignThreads) {
+            const int m = n + d;
+            uint32_t w = 0;
+            if (m >= 0 && m < L) {
+                uint32_t s = (uint16_t)s16[m] ^ x16;
+                float2 y = rot_rn(make_float2(i8_to_f32(sext8(s, 0)), i8_to_f32(sext8(s, 1))), p);
+                w = (uint32_t)(f32_to_i8(y.x) & 0xFF) | ((uint32_t)(f32_to_i8(y.y) & 0xFF) << 8);
+            }
+            o16[n] = (uint16_t)w;
+        }
+    }
+}
+
+// ---- per-op kernels (class cdsp) ---------------------------------------------------------------
+__global__ void k_op_convtosigned(const uint32_t *in, uint32_t *out, int nwords)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < nwords) out[i] = in[i] ^ 0x80808080u;
+}
+__global__ void k_op_convtofloat(float *out, const int8_t *in, int n)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = i8_to_f32((int)in[i]);
+}
+__global__ void k_op_scalarmul(float2 *out, const float2 *in, float2 s, int n)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = rot_rn(in[i], s);
+}
+__global__ void k_op_convto8bit(int8_t *out, const float *in, int nfloats)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < nfloats) out[i] = (int8_t)f32_to_i8(in[i]);
+}
+__global__ void k_op_magsquared(float *out, const float2 *in, int n)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = __fadd_rn(__fmul_rn(in[i].x, in[i].x), __fmul_rn(in[i].y, in[i].y));
+}
+__global__ void k_op_conjugatemul(float2 *out, const float2 *a, const float2 *b, int n)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        float2 x = a[i], y = b[i];
+        out[i] = make_float2(__fadd_rn(__fmul_rn(x.x, y.x), __fmul_rn(x.y, y.y)),
+                             __fsub_rn(__fmul_rn(x.y, y.x), __fmul_rn(x.x, y.y)));
+    }
+}
+// single workgroup: pairwise (tree) sum -- differs from VOLK's sequential accumulator only in
+// rounding; compared to tolerance (SURVEY 8 note: a10 is never bit-comparable)
+__global__ __launch_bounds__(1024) void k_op_conj_dot(float *res, const float2 *a, const float2 *b, int n)
+{
+    __shared__ double sre[16], sim[16];
+    double re = 0.0, im = 0.0;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        float2 x = a[i], y = b[i];
+        re += (double)x.x * y.x + (double)x.y * y.y;
+        im += (double)x.y * y.x - (double)x.x * y.y;
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        re += __shfl_xor(re, off, 64);
+        im += __shfl_xor(im, off, 64);
+    }
+    if ((threadIdx.x & 63) == 0) { sre[threadIdx.x >> 6] = re; sim[threadIdx.x >> 6] = im; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double r = 0, i = 0;
+        for (int w = 0; w < (int)(blockDim.x >> 6); ++w) { r += sre[w]; i += sim[w]; }
+        res[0] = (float)r;
+        res[1] = (float)i;
+    }
+}
+__global__ __launch_bounds__(1024) void k_op_indexofmax(uint32_t *index, const float *in, int n)
+{
+    __shared__ ArgMax wred[16];
+    ArgMax best = {in[0], 0};
+    for (int i = threadIdx.x; i < n; i += blockDim.x) argmax_take(best, in[i], i);
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        float om = __shfl_xor(best.m, off, 64);
+        int oi = __shfl_xor(best.idx, off, 64);
+        argmax_take(best, om, oi);
+    }
+    if ((threadIdx.x & 63) == 0) wred[threadIdx.x >> 6] = best;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        ArgMax b = wred[0];
+        for (int w = 1; w < (int)(blockDim.x >> 6); ++w) argmax_take(b, wred[w].m, wred[w].idx);
+        *index = (uint32_t)b.idx;
+    }
+}
+
+// batched standalone FFT (cdsp::fft): one workgroup per transform, natural-order output
+template <int LOG2N, int DIR>
+__global__ __launch_bounds__(FftGeom<LOG2N>::THREADS) void k_op_fft(float2 *__restrict__ out,
+                                                                    const float2 *__restrict__ in,
+                                                                    const float2 *__restrict__ tw)
+{
+    using G = FftGeom<LOG2N>;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float2 *A = reinterpret_cast<float2 *>(smem);
+    const int tid = threadIdx.x;
+    const float2 *src = in + (size_t)blockIdx.x * G::N;
+    float2 *dst = out + (size_t)blockIdx.x * G::N;
+    for (int j = tid; j < G::N; j += G::THREADS) A[j] = src[j];
+    __syncthreads();
+    fft_dif_range<LOG2N, DIR, 0, G::NPASS>(A, tw, tid);
+    for (int j = tid; j < G::N; j += G::THREADS) dst[digit_reverse<LOG2N>(j)] = A[j];
+}
+
+} // namespace crsdr

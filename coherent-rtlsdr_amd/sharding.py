@@ -1,0 +1,82 @@
+"""Row sharding of the receive matrix across GPUs and its reassembly.
+
+Every signal row depends only on itself and on row 0 (src/ccoherent.cc:177-179,189-234,262-283),
+so rank g owns a contiguous slab of signal rows, the 2L-byte reference block is replicated,
+and the only exchange step of the path is one gather of the int8 slabs (2 bytes per sample,
+never cf32) plus 16 bytes per row of {lag, mag, phasor}.  torch.distributed is the transport:
+backend "nccl" is RCCL over xGMI on ROCm; "gloo" is used by the CPU tests.
+
+The gather root rotates per block (block b is assembled on rank b mod G): a fixed root would
+ingest (G-1)/G of every block over its own xGMI links and cap scaling; rotating spreads the
+ingest over all ranks.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+
+
+@dataclass(frozen=True)
+class Slab:
+    row_begin: int   # first owned signal row (global index, >= 1)
+    row_count: int   # owned signal rows
+    rows_per_rank: int
+
+
+def slab_for_rank(nrows: int, world: int, rank: int) -> Slab:
+    """Contiguous equal slabs of the nrows-1 signal rows; world must divide them."""
+    nsig = nrows - 1
+    if world < 1 or not (0 <= rank < world):
+        raise ValueError(f"bad rank {rank} of {world}")
+    if nsig % world:
+        raise ValueError(f"{nsig} signal rows do not split evenly over {world} ranks")
+    per = nsig // world
+    return Slab(1 + rank * per, per, per)
+
+
+def gather_root(block_index: int, world: int) -> int:
+    return block_index % world
+
+
+def matrix_view(packet, nrows: int, B: int):
+    """[nrows][B] int8 view of the matrix inside a packet tensor (1-D int8/uint8, torch)."""
+    off = 16 + 4 * nrows
+    return packet[off: off + nrows * B].view(nrows, B)
+
+
+def gather_matrix(packet, nrows: int, B: int, slab: Slab, root: int, group=None, async_op: bool = False):
+    """Gather every rank's slab of matrix rows into `packet` on `root`.
+
+    packet: this rank's full-size packet tensor; the plan has written rows
+    [slab.row_begin, slab.row_begin + slab.row_count) (and row 0 + header, identical on every
+    rank).  On the root the other ranks' slabs land in place; other ranks only send.
+    Returns the torch.distributed work handle (or None).
+    """
+    import torch.distributed as dist
+
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    if world == 1:
+        return None
+    m = matrix_view(packet, nrows, B)
+    mine = m[slab.row_begin: slab.row_begin + slab.row_count]
+    if rank == root:
+        per = slab.rows_per_rank
+        out = [m[1 + r * per: 1 + (r + 1) * per] for r in range(world)]
+        return dist.gather(mine, gather_list=out, dst=root, group=group, async_op=async_op)
+    return dist.gather(mine, gather_list=None, dst=root, group=group, async_op=async_op)
+
+
+def gather_scalars(local, slab: Slab, root: int, group=None):
+    """Gather per-row scalars (a [nrows, k] tensor holding this rank's rows) onto root in place."""
+    import torch.distributed as dist
+
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    if world == 1:
+        return None
+    mine = local[slab.row_begin: slab.row_begin + slab.row_count]
+    if rank == root:
+        per = slab.rows_per_rank
+        out = [local[1 + r * per: 1 + (r + 1) * per] for r in range(world)]
+        return dist.gather(mine, gather_list=out, dst=root, group=group)
+    return dist.gather(mine, gather_list=None, dst=root, group=group)

@@ -1,0 +1,200 @@
+/*
+ * crsdr.h -- C ABI of the MI355X-native coherent-alignment engine (libcrsdr.so).
+ *
+ * Drop-in boundary for ONE path of mlaaks/coherent-rtlsdr: the ccoherent/cdsp DSP path
+ * (int8 IQ -> complex float -> zero-padded FFT cross-correlation against the reference-noise
+ * row -> argmax lag + magnitude -> phase estimate -> rotate (+shift) -> re-quantise into the
+ * N x L receive matrix that cpacketize publishes).  Everything else of the reference (USB,
+ * tuner control, console, ZMQ sockets) stays where it is.
+ *
+ * Two levels, mirroring the reference's own plug point (class cdsp is "wraps to volk kernels.
+ * In future, these could be mapped to custom code", src/cdsp.cc:19; the RASPBERRYPI build
+ * already swaps the FFT backend behind fft_scheme, include/cdsp.h:23-32):
+ *   (i)  per-op entry points, one per cdsp static method   -> unit parity, drop-in for cdsp.cc
+ *   (ii) a batched plan replacing ccoherent::{ctor,queuelag,computelag} plus the per-row
+ *        csdrdevice::{convtofloat,est_phasecorrect,phasecorrect} and cpacketize::write chain
+ *        (src/ccoherent.cc:245-294), because per-op launches would be launch-bound.
+ *
+ * Conventions (reference units): blocksize B = int8 values per row per block = FFT length in
+ * complex points; L = B/2 complex samples per row; row 0 = reference-noise channel.
+ * Complex arrays are interleaved float (re,im) -- layout-identical to std::complex<float>,
+ * fftwf_complex and lv_32fc_t (src/ccoherent.cc:65).
+ * Every function returns 0 on success or a negative CRSDR_E* code; nothing throws across the
+ * ABI; crsdr_last_error() gives the text for the calling thread's last failure.
+ * There is NO CPU fallback: without a usable HIP device every compute entry point fails with
+ * CRSDR_ENODEV.
+ */
+#ifndef CRSDR_H
+#define CRSDR_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CRSDR_ABI_VERSION 1
+
+enum {
+    CRSDR_OK = 0,
+    CRSDR_EINVAL = -1,  /* bad argument (NULL, non power-of-two size, out of range) */
+    CRSDR_ENOMEM = -2,  /* host or device allocation failed */
+    CRSDR_EHIP = -3,    /* a HIP runtime call or kernel launch failed */
+    CRSDR_ENODEV = -4,  /* no HIP device available */
+    CRSDR_ESTATE = -5   /* call sequence error (fetch before submit, ...) */
+};
+
+int crsdr_abi_version(void);
+const char *crsdr_last_error(void);
+int crsdr_device_count(int *count);
+
+/* ------------------------------------------------------------------------------------------
+ * (i) per-op entry points == class cdsp (include/cdsp.h:36-71).  Host pointers in and out;
+ *     each call stages through device memory on the current device (default stream) and
+ *     returns when the result is in `out`.  Note the reference's mixed units for n.
+ * ---------------------------------------------------------------------------------------- */
+
+/* cdsp::convtosigned(const uint8_t*,const uint8_t*,int)  include/cdsp.h:40, src/cdsp.cc:21-34
+ * out[i] = in[i] ^ 0x80, n bytes (n % 8 == 0 like the reference's 64-bit loop). */
+int crsdr_convtosigned(const uint8_t *in, uint8_t *out, int n);
+
+/* cdsp::convtofloat(const float*,const int8_t*,int) and the complex overload
+ * include/cdsp.h:41,45, src/cdsp.cc:36-44.  n = number of int8 values (= floats written). */
+int crsdr_convtofloat(float *out, const int8_t *s8bit, int n);
+
+/* cdsp::scalarmul  include/cdsp.h:47, src/cdsp.cc:46-49.  n = complex count. */
+int crsdr_scalarmul(float *out, const float *in, float scalar_re, float scalar_im, int n);
+
+/* cdsp::convto8bit  include/cdsp.h:43, src/cdsp.cc:51-54.  n = complex count (2n bytes out). */
+int crsdr_convto8bit(int8_t *out, const float *in, int n);
+
+/* cdsp::conj_dotproduct  include/cdsp.h:49, src/cdsp.cc:61-66.  res[0..1] = sum a*conj(b). */
+int crsdr_conj_dotproduct(float *res, const float *a, const float *b, int n);
+
+/* cdsp::magsquared  include/cdsp.h:61, src/cdsp.cc:100-103.  n = complex count. */
+int crsdr_magsquared(float *out, const float *in, int n);
+
+/* cdsp::conjugatemul  include/cdsp.h:63, src/cdsp.cc:105-108.  out = in1 * conj(in2). */
+int crsdr_conjugatemul(float *out, const float *in1, const float *in2, int n);
+
+/* cdsp::indexofmax(float*,int)  include/cdsp.h:68, src/cdsp.cc:135-139: first strict maximum. */
+int crsdr_indexofmax(uint32_t *index, const float *in, int n);
+
+/* cdsp::fft(out,in,fft_scheme*)  include/cdsp.h:65, src/cdsp.cc:110-120, with the plan geometry
+ * of src/ccoherent.cc:78-93 passed explicitly instead of an fftwf_plan: `howmany` contiguous
+ * transforms of n complex points (dist n, stride 1), sign -1 = FFTW_FORWARD, +1 =
+ * FFTW_BACKWARD, unnormalised, out of place.  n: power of two, 16 <= n <= 16384 (LDS-resident)
+ * or 2^15 <= n <= 2^22 (multi-pass, HBM-streaming). */
+int crsdr_fft(float *out, const float *in, int n, int sign, int howmany);
+
+/* ------------------------------------------------------------------------------------------
+ * (ii) batched plan == ccoherent + per-row csdrdevice DSP members + cpacketize::write
+ * ---------------------------------------------------------------------------------------- */
+
+enum {
+    CRSDR_MODE_FAITHFUL = 0, /* reference order of operations: lag reported, samples not
+                                shifted (the lag feeds the resampler servo, src/ccontrol.cc:93-119),
+                                phase estimated at zero offset */
+    CRSDR_MODE_DIGITAL = 1   /* north_star "rotate/shift": row k is shifted by its lag, the
+                                phase is estimated over the overlap, then rotate + quantise */
+};
+
+enum {
+    CRSDR_MEM_HOST = 0,   /* pointer is host memory: the plan copies H2D / D2H */
+    CRSDR_MEM_DEVICE = 1  /* pointer is device memory on the plan's device */
+};
+
+/* crsdr_plan_submit flags */
+enum {
+    CRSDR_REFNOISE_ENABLED = 1u << 0, /* crefnoise::isenabled(), gate of src/ccoherent.cc:271 */
+    CRSDR_OFFSET_BINARY = 1u << 1,    /* input is librtlsdr's raw uint8: fuse cdsp::convtosigned
+                                         (x ^ 0x80, include/common.h:114-122) into the loads */
+    CRSDR_INPUT_READY = 1u << 2,      /* device input is already complete: the reference-spectrum
+                                         kernel need not wait for earlier work on the stream */
+    CRSDR_NO_LAG = 1u << 3            /* no row requests a lag this block ("locked" steady state,
+                                         src/ccontrol.cc:117-120): phase path only, no FFT */
+};
+
+typedef struct crsdr_plan crsdr_plan;
+
+typedef struct crsdr_plan_desc {
+    int32_t nrows;      /* N: reference row + signal rows in the receive matrix (hdr0::N) */
+    int32_t blocksize;  /* B: int8 values per row per block; power of two, 16..16384 */
+    int32_t mode;       /* CRSDR_MODE_* */
+    int32_t device;     /* HIP device ordinal */
+    int32_t row_begin;  /* first signal row this plan owns (>= 1); 0 = default (1) */
+    int32_t row_count;  /* signal rows owned; 0 = default (all: nrows - row_begin).  Multi-GPU:
+                           rank g owns a contiguous slab, the ref row is replicated */
+    uint32_t reserved[2];
+} crsdr_plan_desc;
+
+/* ccoherent::ccoherent (src/ccoherent.cc:32-95): allocates every device buffer, twiddle table,
+ * stream and event; nothing is allocated on the per-block path afterwards. */
+int crsdr_plan_create(crsdr_plan **plan, const crsdr_plan_desc *desc);
+/* ccoherent::~ccoherent (src/ccoherent.cc:97-112) */
+int crsdr_plan_destroy(crsdr_plan *plan);
+/* back to construction state: phasecorr = phasecorrprev = 1+0j, lag = 0 (src/csdrdevice.cc:36-40) */
+int crsdr_plan_reset(crsdr_plan *plan);
+
+/* Run the plan's kernels on a caller-owned hipStream_t (e.g. the stream an RCCL gather is
+ * enqueued on); NULL restores the plan's own stream. */
+int crsdr_plan_set_stream(crsdr_plan *plan, void *hip_stream);
+
+/* One ccoherent::threadf iteration (src/ccoherent.cc:245-294), asynchronous.
+ *   rows      [nrows][B] int8 (uint8 with CRSDR_OFFSET_BINARY), row 0 = reference; a plan that
+ *             owns a slab reads only row 0 and its own rows.
+ *   mem_kind  CRSDR_MEM_HOST (copied) or CRSDR_MEM_DEVICE (read in place; must stay valid
+ *             until the next fetch/sync).
+ *   readcnt   [nrows] host array copied into the packet (cpacketize::write, src/cpacketizer.cc:
+ *             142,163), or NULL: every row gets `seq`.
+ *   lag_mask  [nrows] host bytes, non-zero = csdrdevice::is_lagrequested() (src/ccoherent.cc:266);
+ *             NULL = every owned signal row.  Unlike the reference there is no nfft = 8 cap
+ *             (src/ccoherent.cc:124): every requested row is cross-correlated in this block.
+ *   seq       hdr0::globalseqn for this block (src/cpacketizer.cc:113). */
+int crsdr_plan_submit(crsdr_plan *plan, const void *rows, int mem_kind, const uint32_t *readcnt,
+                      const uint8_t *lag_mask, uint32_t seq, uint32_t flags);
+
+/* Wait for the last submitted block and copy results to host arrays (any may be NULL):
+ *   lag    [nrows] int32  idx - L, what csdrdevice::set_lag receives (src/ccoherent.cc:232)
+ *   mag    [nrows] float  sqrt(peak / L)                         (src/ccoherent.cc:204)
+ *   frac   [nrows] float  3-point parabolic peak offset in samples (extra output; the reference
+ *                         computes and discards its own variant, src/ccoherent.cc:206-219)
+ *   phasor [nrows][2]     csdrdevice::get_phasecorrect() -- the port-5557 debug payload
+ *                         (src/cpacketizer.cc:127,131-134); entry 0 is 0
+ *   packet crsdr_plan_packet_bytes() bytes: hdr0{seq,N,L,0} + u32 readcnt[N] + int8 [N][B]
+ *          (include/cpacketizer.h:32-37; parser matlabclient/zmqsdr.c:118-144).
+ * Rows outside the plan's slab hold whatever the bound buffer held (zeros by default). */
+int crsdr_plan_fetch(crsdr_plan *plan, int32_t *lag, float *mag, float *frac, float *phasor,
+                     int8_t *packet);
+
+/* Block until everything submitted so far has finished (no copies). */
+int crsdr_plan_sync(crsdr_plan *plan);
+
+size_t crsdr_plan_packet_bytes(const crsdr_plan *plan);   /* 16 + 4N + N*B */
+size_t crsdr_plan_matrix_offset(const crsdr_plan *plan);  /* 16 + 4N */
+
+/* Device-resident results for pipelines that never leave HBM (multi-GPU gather, benchmarks).
+ * The packet pointer is 4-byte aligned and the matrix inside it 256-byte aligned. */
+int crsdr_plan_device_buffers(crsdr_plan *plan, void **packet, void **lag, void **mag,
+                              void **frac, void **phasor);
+/* Write the packets of later submits into a caller-owned device buffer instead (>= packet_bytes,
+ * matrix start 4-byte aligned); NULL restores the plan's own buffer.  Does not synchronise:
+ * double-buffering against a gather in flight is the caller's business. */
+int crsdr_plan_bind_packet(crsdr_plan *plan, void *device_packet);
+
+/* Elapsed GPU milliseconds between the start of the first and the end of the last kernel of
+ * the most recent submit (hipEvents on the plan's stream). */
+int crsdr_plan_last_elapsed_ms(crsdr_plan *plan, float *ms);
+
+/* Per-kernel timing with hipEvents recorded on the stream each kernel is launched on.
+ * enable: keep event pairs for the last `slots` submits (0 disables).  kernel_times: copy the
+ * durations (ms) of kernel `which` for the submits recorded since enable, oldest first. */
+enum { CRSDR_KERNEL_REF_SPECTRUM = 0, CRSDR_KERNEL_XCORR_LAG = 1, CRSDR_KERNEL_ALIGN_QUANT = 2 };
+int crsdr_plan_enable_profiling(crsdr_plan *plan, int slots);
+int crsdr_plan_kernel_times(crsdr_plan *plan, int which, float *ms, int capacity, int *count);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CRSDR_H */

@@ -426,7 +426,7 @@ static void write_header(const orc_engine *e, int8_t *packet, const uint32_t *re
     uint32_t h[4] = { seq, (uint32_t)e->nrows, (uint32_t)e->L, 0u };
     memcpy(packet, h, 16);
     for (int r = 0; r < e->nrows; r++) {
-        uint32_t v = readcnt ? readcnt[r] : 0u;               /* src/cpacketizer.cc:142,163 */
+        uint32_t v = readcnt ? readcnt[r] : seq;              /* src/cpacketizer.cc:142,163 */
         memcpy(packet + 16 + 4 * (size_t)r, &v, 4);
     }
 }

@@ -72,7 +72,7 @@ void orc_engine_reset(orc_engine *e);
 
 /* One block.
  *   rows      [nrows][B] int8, row 0 = reference noise channel.
- *   readcnt   [nrows] per-row block counters copied into the packet, or NULL (zeros).
+ *   readcnt   [nrows] per-row block counters copied into the packet, or NULL (every row: seq).
  *   lag_mask  [nrows] non-zero = csdrdevice::is_lagrequested() for that row
  *             (src/ccoherent.cc:266), entry 0 ignored; NULL = every signal row.
  *   refnoise_enabled  crefnoise::isenabled() gate of src/ccoherent.cc:271.

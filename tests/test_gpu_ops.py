@@ -1,0 +1,95 @@
+"""GPU parity, per-op level: every cdsp entry point of the C ABI (include/crsdr.h) against the
+CPU oracle on the same inputs.  Bar: bit-exact for integer / byte / index results and for the
+single-rounding fp32 ops; stated tolerance for reductions and the FFT."""
+import importlib
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def b():
+    binding = importlib.import_module("coherent-rtlsdr_amd.binding")
+    if binding.device_count() < 1:
+        pytest.fail("no HIP device: the product path has no CPU fallback")
+    return binding
+
+
+def _crand(rng, *shape):
+    return (rng.standard_normal(shape) + 1j * rng.standard_normal(shape)).astype(np.complex64)
+
+
+def test_convtosigned_bitexact(b, oracle):
+    u = np.random.default_rng(0).integers(0, 256, 4096, dtype=np.uint8)
+    assert np.array_equal(b.convtosigned(u), oracle.convtosigned(u))
+
+
+def test_convtofloat_bitexact(b, oracle):
+    i8 = np.tile(np.arange(-128, 128, dtype=np.int8), 8)
+    assert np.array_equal(b.convtofloat(i8).view(np.float32), oracle.convtofloat(i8).view(np.float32))
+
+
+def test_scalarmul_conjmul_magsq_bitexact(b, oracle):
+    rng = np.random.default_rng(1)
+    a, c = _crand(rng, 5000), _crand(rng, 5000)
+    s = np.complex64(0.6 - 0.3j)
+    assert np.array_equal(b.scalarmul(a, s).view(np.float32), oracle.scalarmul(a, s).view(np.float32))
+    assert np.array_equal(b.conjugatemul(a, c).view(np.float32), oracle.conjugatemul(a, c).view(np.float32))
+    assert np.array_equal(b.magsquared(a), oracle.magsquared(a))
+
+
+def test_convto8bit_bitexact_including_ties_and_saturation(b, oracle):
+    rng = np.random.default_rng(2)
+    x = (_crand(rng, 4096) * np.float32(0.7)).astype(np.complex64)
+    xf = x.view(np.float32)
+    xf[:16] = np.array([0.5, 1.5, 2.5, -0.5, -1.5, -2.5, 126.5, 127.5, 300, -128.5, -129, -300, 0, 63.5, -63.5, 1e9],
+                       dtype=np.float32) / np.float32(127.0)
+    assert np.array_equal(b.convto8bit(x), oracle.convto8bit(x))
+
+
+def test_conj_dotproduct_tolerance(b, oracle):
+    rng = np.random.default_rng(3)
+    a, c = _crand(rng, 8192), _crand(rng, 8192)
+    got, exp = b.conj_dotproduct(a, c), oracle.conj_dotproduct(a, c)
+    ref = np.sum(a.astype(np.complex128) * np.conj(c.astype(np.complex128)))
+    scale = np.sum(np.abs(a) * np.abs(c))
+    assert abs(got - ref) <= 1e-6 * scale          # tree reduction in fp64 partials
+    assert abs(got - exp) <= 2e-4 * scale          # VOLK-generic sequential fp32 accumulator
+
+
+def test_indexofmax_first_maximum(b, oracle):
+    rng = np.random.default_rng(4)
+    m = rng.random(16384).astype(np.float32)
+    assert b.indexofmax(m) == oracle.indexofmax(m)
+    m[[100, 9000, 16383]] = 7.0                     # tie -> lowest index
+    assert b.indexofmax(m) == 100 == oracle.indexofmax(m)
+    m[:] = 1.0
+    assert b.indexofmax(m) == 0
+
+
+@pytest.mark.parametrize("n", [16, 32, 64, 128, 256, 512, 1024, 2048, 4096, 8192, 16384])
+@pytest.mark.parametrize("sign", [-1, 1])
+def test_fft_vs_oracle_and_fp64(b, oracle, n, sign):
+    # tolerance: relative L2 <= 1e-6 against fp64, and against the fp32 oracle
+    rng = np.random.default_rng(n * 3 + sign)
+    x = _crand(rng, 5, n)
+    got = b.fft(x, sign)
+    x64 = x.astype(np.complex128)
+    ref = np.fft.fft(x64, axis=-1) if sign < 0 else np.fft.ifft(x64, axis=-1) * n
+    assert np.linalg.norm(got - ref) / np.linalg.norm(ref) <= 1e-6
+    exp = oracle.fft(x, sign)
+    assert np.linalg.norm(got - exp) / np.linalg.norm(ref) <= 1e-6
+
+
+def test_fft_linearity_and_roundtrip(b):
+    # size-independent properties at the full block size: linearity and ifft(fft(x)) = N x
+    n = 16384
+    rng = np.random.default_rng(5)
+    x, y = _crand(rng, n), _crand(rng, n)
+    lhs = b.fft(x + np.complex64(2) * y)
+    rhs = b.fft(x) + np.complex64(2) * b.fft(y)
+    assert np.linalg.norm(lhs - rhs) / np.linalg.norm(rhs) <= 1e-6
+    back = b.fft(b.fft(x, -1), +1) / np.float32(n)
+    assert np.linalg.norm(back - x) / np.linalg.norm(x) <= 1e-6
