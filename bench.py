@@ -40,7 +40,8 @@ def parse():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--nsig", type=int, default=1024, help="signal rows (channels) in the receive matrix")
     ap.add_argument("--L", type=int, default=8192, help="complex samples per row per block")
-    ap.add_argument("--nbuf", type=int, default=4, help="distinct resident input blocks rotated through")
+    ap.add_argument("--nbuf", type=int, default=16, help="distinct resident input blocks rotated through")
+    ap.add_argument("--batch", type=int, default=8, help="consecutive blocks per submit (one launch set per batch)")
     ap.add_argument("--mode", choices=["digital", "faithful"], default="digital")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the locked-mode / large-working-set extras")
@@ -78,49 +79,65 @@ def main():
     mode = b.MODE_DIGITAL if args.mode == "digital" else b.MODE_FAITHFUL
 
     # ---- synthetic resident input: nbuf distinct blocks, each rank fills row 0 + its slab ----------
+    T = max(1, min(args.batch, args.steps))
+    nbuf = max(T, (args.nbuf // T) * T)           # whole batches, contiguous in HBM
     seed = synth.config_seed(4)
     params = synth.RowParams(nsig, L, seed)
-    d_in = []
-    for t in range(args.nbuf):
+    d_in = torch.empty((nbuf, nrows, B), dtype=torch.uint8, device=dev)
+    for t in range(nbuf):
         rows, _ = synth.make_block(nsig, L, seed, t, params=params) if world == 1 else _make_slab(synth, params, nsig, L, seed, t, slab)
-        d_in.append(torch.from_numpy(rows.view(np.uint8)).to(dev))
+        d_in[t].copy_(torch.from_numpy(rows.view(np.uint8)))
     host_block0 = rows if world == 1 else None
+    block_bytes = nrows * B
 
-    plan = b.Plan(nrows, B, mode, device=local_rank, row_begin=slab.row_begin, row_count=slab.row_count)
+    plan = b.Plan(nrows, B, mode, device=local_rank, row_begin=slab.row_begin, row_count=slab.row_count, max_batch=T)
     stream = torch.cuda.current_stream()
     plan.set_stream(stream.cuda_stream)
-    packets = [torch.zeros(plan.packet_bytes + 64, dtype=torch.uint8, device=dev) for _ in range(2)]
-    # keep the matrix 16-byte aligned inside the torch buffer
+    # two sets of T packets (double-buffered against the gather); matrix of every packet 16-byte aligned
+    pstride = (plan.packet_bytes + 255) // 256 * 256
+    packets = [torch.zeros(pstride * T + 64, dtype=torch.uint8, device=dev) for _ in range(2)]
     pk_off = [(-(p.data_ptr() + plan.matrix_offset)) % 16 for p in packets]
-    pk_view = [p[o: o + plan.packet_bytes] for p, o in zip(packets, pk_off)]
+    pk_view = [[p[o + t * pstride: o + t * pstride + plan.packet_bytes] for t in range(T)] for p, o in zip(packets, pk_off)]
     flags = b.REFNOISE_ENABLED | b.INPUT_READY
-    works = [None, None]
+    works = [[], []]
 
-    def step(i, fl=flags):
-        k = i & 1
-        if works[k] is not None:
-            works[k].wait()          # stream-level: the gather that read this packet buffer is done
-            works[k] = None
-        plan.bind_packet(pk_view[k].data_ptr())
-        plan.submit(d_in[i % args.nbuf].data_ptr(), seq=i, flags=fl)
+    def run_batch(ib, nb, fl=flags):
+        """blocks [ib*T, ib*T + nb) of the stream: one submit, then one gather per block"""
+        k = ib & 1
+        for w in works[k]:
+            w.wait()                 # stream-level: the gathers that read this packet set are done
+        works[k] = []
+        plan.bind_packet(pk_view[k][0].data_ptr(), pstride)
+        first_buf = (ib * T) % nbuf
+        plan.submit(d_in[first_buf].data_ptr(), seq=ib * T, flags=fl, nblocks=nb, block_stride=block_bytes)
         if world > 1:
-            works[k] = sharding.gather_matrix(pk_view[k], nrows, B, slab, sharding.gather_root(i, world), async_op=True)
+            for t in range(nb):
+                w = sharding.gather_matrix(pk_view[k][t], nrows, B, slab, sharding.gather_root(ib * T + t, world), async_op=True)
+                if w is not None:
+                    works[k].append(w)
 
     def fence():
         for k in (0, 1):
-            if works[k] is not None:
-                works[k].wait()
-                works[k] = None
+            for w in works[k]:
+                w.wait()
+            works[k] = []
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    def timed(nsteps, fl=flags, first=0):
+    def run_steps(nsteps, fl=flags):
+        """exactly nsteps blocks, in batches of T (the last batch may be shorter)"""
+        ib, left = 0, nsteps
+        while left > 0:
+            nb = min(T, left)
+            run_batch(ib, nb, fl)
+            ib, left = ib + 1, left - nb
+
+    def timed(nsteps, fl=flags):
         fence()
         t0 = time.perf_counter()
-        for i in range(first, first + nsteps):
-            step(i, fl)
+        run_steps(nsteps, fl)
         fence()
         dt = time.perf_counter() - t0
         if world > 1:
@@ -130,14 +147,15 @@ def main():
         return dt
 
     # ---- warm-up, then the timed region with per-kernel HIP events on the launch streams ----------
-    for i in range(args.warmup):
-        step(i)
+    run_steps(args.warmup)
     fence()
     plan.enable_profiling(min(max(args.steps, 1), 1024))
-    dt = timed(args.steps, first=args.warmup)
+    dt = timed(args.steps)
     k_ms = {name: plan.kernel_times_ms(k) for name, k in
-            (("ref_spectrum", b.KERNEL_REF_SPECTRUM), ("xcorr_lag", b.KERNEL_XCORR_LAG), ("align_quant", b.KERNEL_ALIGN_QUANT))}
+            (("ref_spectrum", b.KERNEL_REF_SPECTRUM), ("xcorr_lag", b.KERNEL_XCORR_LAG), ("phase_dot", b.KERNEL_PHASE_DOT),
+             ("align_quant", b.KERNEL_ALIGN_QUANT))}
     plan.enable_profiling(0)
+    full_batches = args.steps // T      # launches that carried exactly T blocks come first
     blocks_per_s = args.steps / dt
 
     # parity spot-check of the timed path against the injected delays (every rank, its slab)
@@ -148,8 +166,10 @@ def main():
     result = None
     if rank == 0:
         A_block = nrows * B                                   # algorithmic bytes per block
-        k1 = float(np.mean(k_ms["xcorr_lag"])) if len(k_ms["xcorr_lag"]) else float("nan")
-        k1_bytes = slab.row_count * B                         # int8 bytes one K1 launch consumes
+        k1s = k_ms["xcorr_lag"][:full_batches] if full_batches else k_ms["xcorr_lag"]
+        k1 = float(np.mean(k1s)) if len(k1s) else float("nan")
+        tb = T if full_batches else args.steps
+        k1_bytes = tb * slab.row_count * B                    # int8 bytes one K1 launch consumes (tb blocks)
         achieved = k1_bytes / (k1 * 1e-3) / 1e9               # GB/s
         flop_row = 2 * 5 * B * np.log2(B) + 9 * B + 16 * L    # SURVEY 8d VALU view, per signal row
         result = {
@@ -158,13 +178,14 @@ def main():
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"cfg4: 1 ref + {nsig} signal rows x {L} int8 IQ samples per block, track cadence "
                                    f"(FFT xcorr every block), {args.mode} mode, inputs resident in HBM, "
-                                   f"{args.nbuf} rotating input blocks",
-                       "rows": nrows, "L": L, "fft_len": B, "mode": args.mode,
+                                   f"{nbuf} rotating input blocks, {T} blocks per submit",
+                       "rows": nrows, "L": L, "fft_len": B, "mode": args.mode, "batch": T,
                        "parallelism": f"rows sharded x{world}, ref replicated, rotating-root int8 gather" if world > 1 else "single GPU"},
             "roofline": {"bound": "hbm", "kernel": "k_xcorr_lag", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": _committed_traffic("k_xcorr_lag"),
                          "algorithmic_bytes_per_launch": k1_bytes, "avg_launch_ms": k1,
-                         "valu_frac": (slab.row_count * flop_row / (k1 * 1e-3)) / (FP32_VALU_PEAK_TF * 1e12),
+                         "valu_frac": (tb * slab.row_count * flop_row / (k1 * 1e-3)) / (FP32_VALU_PEAK_TF * 1e12),
+                         "blocks_per_launch": tb,
                          "note": "track cadence is fp32-VALU/LDS bound (157 flop per input byte vs machine balance 20); "
                                  "the HBM-bound regime of this path is the locked mode below"},
             "whole_path": {"algorithmic_bytes_per_block": A_block,
@@ -176,20 +197,21 @@ def main():
     # ---- extras: locked steady state (phase path only) ---------------------------------------------
     if not args.no_extras:
         fl_locked = flags | b.NO_LAG
-        for i in range(5):
-            step(i, fl_locked)
+        run_steps(2 * T, fl_locked)
         plan.enable_profiling(256)
-        n_l = max(args.steps, 200)
+        n_l = max(args.steps, 200) // T * T
         dt_l = timed(n_l, fl_locked)
         k2 = plan.kernel_times_ms(b.KERNEL_ALIGN_QUANT)
+        k2a = plan.kernel_times_ms(b.KERNEL_PHASE_DOT)
         plan.enable_profiling(0)
         if rank == 0:
             k2m = float(np.mean(k2))
-            rd = (slab.row_count + 1) * B
+            rd = T * (slab.row_count + 1) * B
             result["locked"] = {"blocks_per_s": n_l / dt_l, "ms_per_step": 1e3 * dt_l / n_l,
                                 "roofline": {"bound": "hbm", "kernel": "k_align_quant", "achieved": rd / (k2m * 1e-3) / 1e9,
                                              "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": rd / (k2m * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                              "read_plus_write_GBs": 2 * rd / (k2m * 1e-3) / 1e9, "avg_launch_ms": k2m,
+                                             "phase_dot_avg_launch_ms": float(np.mean(k2a)), "blocks_per_launch": T,
                                              "traffic": _committed_traffic("k_align_quant")},
                                 "hbm_read_frac": (nrows * B) * (n_l / dt_l) / (world * HBM_PEAK_GBS * 1e9)}
 

@@ -28,8 +28,9 @@ ABI_SYMBOLS = [
     "crsdr_plan_submit", "crsdr_plan_fetch", "crsdr_plan_sync", "crsdr_plan_packet_bytes",
     "crsdr_plan_matrix_offset", "crsdr_plan_device_buffers", "crsdr_plan_bind_packet",
     "crsdr_plan_last_elapsed_ms", "crsdr_plan_enable_profiling", "crsdr_plan_kernel_times",
+    "crsdr_plan_submit_batch", "crsdr_plan_fetch_block", "crsdr_plan_packet_stride",
 ]
-KERNEL_REF_SPECTRUM, KERNEL_XCORR_LAG, KERNEL_ALIGN_QUANT = 0, 1, 2
+KERNEL_REF_SPECTRUM, KERNEL_XCORR_LAG, KERNEL_PHASE_DOT, KERNEL_ALIGN_QUANT = 0, 1, 2, 3
 
 
 class CrsdrError(RuntimeError):
@@ -50,7 +51,7 @@ def build(force: bool = False) -> str:
 
 class PlanDesc(C.Structure):
     _fields_ = [("nrows", C.c_int32), ("blocksize", C.c_int32), ("mode", C.c_int32), ("device", C.c_int32),
-                ("row_begin", C.c_int32), ("row_count", C.c_int32), ("reserved", C.c_uint32 * 2)]
+                ("row_begin", C.c_int32), ("row_count", C.c_int32), ("max_batch", C.c_int32), ("reserved", C.c_uint32)]
 
 
 _lib = None
@@ -89,7 +90,11 @@ def lib():
     L.crsdr_plan_matrix_offset.argtypes = [vp]
     L.crsdr_plan_matrix_offset.restype = C.c_size_t
     L.crsdr_plan_device_buffers.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]
-    L.crsdr_plan_bind_packet.argtypes = [vp, vp]
+    L.crsdr_plan_bind_packet.argtypes = [vp, vp, C.c_size_t]
+    L.crsdr_plan_submit_batch.argtypes = [vp, vp, C.c_int, C.c_int, C.c_size_t, u32p, u8p, C.c_uint32, C.c_uint32]
+    L.crsdr_plan_fetch_block.argtypes = [vp, C.c_int, i32p, f32p, f32p, f32p, i8p]
+    L.crsdr_plan_packet_stride.argtypes = [vp]
+    L.crsdr_plan_packet_stride.restype = C.c_size_t
     L.crsdr_plan_last_elapsed_ms.argtypes = [vp, C.POINTER(C.c_float)]
     L.crsdr_plan_enable_profiling.argtypes = [vp, C.c_int]
     L.crsdr_plan_kernel_times.argtypes = [vp, C.c_int, f32p, C.c_int, C.POINTER(C.c_int)]
@@ -191,9 +196,9 @@ def fft(x, sign=-1):
 class Plan:
     """crsdr_plan: ccoherent + per-row csdrdevice DSP members + cpacketize::write on one GPU."""
 
-    def __init__(self, nrows, blocksize, mode=MODE_FAITHFUL, device=0, row_begin=0, row_count=0):
-        self.nrows, self.B, self.mode = nrows, blocksize, mode
-        d = PlanDesc(nrows, blocksize, mode, device, row_begin, row_count)
+    def __init__(self, nrows, blocksize, mode=MODE_FAITHFUL, device=0, row_begin=0, row_count=0, max_batch=1):
+        self.nrows, self.B, self.mode, self.max_batch = nrows, blocksize, mode, max_batch
+        d = PlanDesc(nrows, blocksize, mode, device, row_begin, row_count, max_batch, 0)
         h = C.c_void_p()
         _check(lib().crsdr_plan_create(C.byref(h), C.byref(d)))
         self._h = h
@@ -204,31 +209,37 @@ class Plan:
     def set_stream(self, hip_stream: int | None):
         _check(lib().crsdr_plan_set_stream(self._h, C.c_void_p(hip_stream or 0)))
 
-    def submit(self, rows, readcnt=None, lag_mask=None, seq=0, flags=REFNOISE_ENABLED):
-        """rows: numpy int8/uint8 [nrows][B] (host) or an int device pointer."""
+    def submit(self, rows, readcnt=None, lag_mask=None, seq=0, flags=REFNOISE_ENABLED, nblocks=None, block_stride=0):
+        """rows: numpy int8/uint8 [nrows][B] (or [nblocks][nrows][B]) on the host, or an int device pointer."""
         rc_arr = None if readcnt is None else np.ascontiguousarray(readcnt, dtype=np.uint32)
         mk = None if lag_mask is None else np.ascontiguousarray(lag_mask, dtype=np.uint8)
         if isinstance(rows, (int, np.integer)):
             ptr, kind = C.c_void_p(int(rows)), MEM_DEVICE
+            nb = 1 if nblocks is None else int(nblocks)
         else:
             if rows.dtype not in (np.int8, np.uint8):
                 raise TypeError("rows must be int8 (or offset-binary uint8)")
             keep = np.ascontiguousarray(rows)
-            assert keep.shape == (self.nrows, self.B)
+            if keep.ndim == 2:
+                keep = keep[None]
+            assert keep.shape[1:] == (self.nrows, self.B)
+            nb = keep.shape[0] if nblocks is None else int(nblocks)
             self._keep.append(keep)          # stays alive until the next fetch()/sync()
             ptr, kind = C.c_void_p(keep.ctypes.data), MEM_HOST
-        _check(lib().crsdr_plan_submit(self._h, ptr, kind, _p(rc_arr, C.c_uint32), _p(mk, C.c_uint8), int(seq), int(flags)))
+        _check(lib().crsdr_plan_submit_batch(self._h, ptr, kind, nb, int(block_stride), _p(rc_arr, C.c_uint32),
+                                             _p(mk, C.c_uint8), int(seq), int(flags)))
 
-    def fetch(self, want_packet=True):
+    def fetch(self, want_packet=True, block=-1):
         n = self.nrows
         lag = np.zeros(n, dtype=np.int32)
         mag = np.zeros(n, dtype=np.float32)
         frac = np.zeros(n, dtype=np.float32)
         ph = np.zeros(2 * n, dtype=np.float32)
         pkt = np.zeros(self.packet_bytes, dtype=np.int8) if want_packet else None
-        _check(lib().crsdr_plan_fetch(self._h, _p(lag, C.c_int32), _p(mag, C.c_float), _p(frac, C.c_float),
-                                      _p(ph, C.c_float), _p(pkt, C.c_int8)))
-        self._keep.clear()
+        _check(lib().crsdr_plan_fetch_block(self._h, int(block), _p(lag, C.c_int32), _p(mag, C.c_float), _p(frac, C.c_float),
+                                            _p(ph, C.c_float), _p(pkt, C.c_int8)))
+        if block == -1:
+            self._keep.clear()
         return dict(lag=lag, mag=mag, frac=frac, phasor=ph.view(np.complex64), packet=pkt,
                     matrix=None if pkt is None else pkt[self.matrix_offset:].reshape(self.nrows, self.B))
 
@@ -248,8 +259,12 @@ class Plan:
         _check(lib().crsdr_plan_device_buffers(self._h, *[C.byref(p) for p in ptrs]))
         return dict(zip(("packet", "lag", "mag", "frac", "phasor"), [p.value for p in ptrs]))
 
-    def bind_packet(self, device_ptr: int | None):
-        _check(lib().crsdr_plan_bind_packet(self._h, C.c_void_p(device_ptr or 0)))
+    def bind_packet(self, device_ptr: int | None, packet_stride: int = 0):
+        _check(lib().crsdr_plan_bind_packet(self._h, C.c_void_p(device_ptr or 0), int(packet_stride)))
+
+    @property
+    def packet_stride(self) -> int:
+        return int(lib().crsdr_plan_packet_stride(self._h))
 
     def last_elapsed_ms(self) -> float:
         ms = C.c_float(0)

@@ -81,6 +81,27 @@ static int make_twiddles(int n, float2 **d_tw)
     return CRSDR_OK;
 }
 
+// x14 tables: twA[j][t] = W_16384^(t 2^j), t < 512; twB[j][n] = W_512^(n 2^j), n < 16; j < 5
+static int make_twiddles14(float2 **d_twA, float2 **d_twB)
+{
+    std::vector<float2> a(5 * 512), b(5 * 16);
+    for (int j = 0; j < 5; ++j) {
+        for (int t = 0; t < 512; ++t) {
+            double ang = 2.0 * M_PI * (double)(t << j) / 16384.0;
+            a[j * 512 + t] = make_float2((float)std::cos(ang), (float)(-std::sin(ang)));
+        }
+        for (int n = 0; n < 16; ++n) {
+            double ang = 2.0 * M_PI * (double)(n << j) / 512.0;
+            b[j * 16 + n] = make_float2((float)std::cos(ang), (float)(-std::sin(ang)));
+        }
+    }
+    HIP_TRY(hipMalloc((void **)d_twA, sizeof(float2) * a.size()));
+    HIP_TRY(hipMalloc((void **)d_twB, sizeof(float2) * b.size()));
+    HIP_TRY(hipMemcpy(*d_twA, a.data(), sizeof(float2) * a.size(), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(*d_twB, b.data(), sizeof(float2) * b.size(), hipMemcpyHostToDevice));
+    return CRSDR_OK;
+}
+
 constexpr int kMinLog2 = 4, kMaxLog2 = 14; // LDS-resident transform sizes: 16 .. 16384 points
 
 template <int LOG2N>
@@ -88,26 +109,44 @@ static constexpr size_t fft_lds_bytes() { return sizeof(float2) * ((size_t)1 << 
 
 // ---- kernel launchers, dispatched on log2(B) ------------------------------------------------------
 template <int LOG2N>
-static hipError_t launch_ref_spectrum(hipStream_t s, const int8_t *ref_row, const float2 *tw, float2 *refspec, uint32_t xor80)
+static hipError_t launch_ref_spectrum(hipStream_t s, int nblocks, const int8_t *rows, size_t block_stride, const float2 *tw,
+                                      float2 *refspec, uint32_t xor80)
 {
     auto kern = k_ref_spectrum<LOG2N>;
     constexpr size_t lds = fft_lds_bytes<LOG2N>();
     hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(kern, dim3(1), dim3(FftGeom<LOG2N>::THREADS), lds, s, ref_row, tw, refspec, xor80);
+    hipLaunchKernelGGL(kern, dim3(nblocks), dim3(FftGeom<LOG2N>::THREADS), lds, s, rows, block_stride, tw, refspec, xor80);
     return hipGetLastError();
 }
 
 template <int LOG2N>
-static hipError_t launch_xcorr_lag(hipStream_t s, int nblocks, const int8_t *rows, const float2 *tw, const float2 *refspec,
-                                   const uint8_t *mask, int row_begin, uint32_t xor80, int32_t *lag, float *mag, float *frac)
+static hipError_t launch_xcorr_lag(hipStream_t s, const XcorrArgs &a, int row_count, const float2 *tw)
 {
     auto kern = k_xcorr_lag<LOG2N>;
     constexpr size_t lds = fft_lds_bytes<LOG2N>();
     hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(kern, dim3(nblocks), dim3(FftGeom<LOG2N>::THREADS), lds, s, rows, tw, refspec, mask, row_begin,
-                       xor80, lag, mag, frac);
+    hipLaunchKernelGGL(kern, dim3(row_count, a.nblocks), dim3(FftGeom<LOG2N>::THREADS), lds, s, a, tw);
+    return hipGetLastError();
+}
+
+static hipError_t launch_ref_spectrum14(hipStream_t s, int nblocks, const int8_t *rows, size_t block_stride, const float2 *twA,
+                                        const float2 *twB, float2 *refspec, uint32_t xor80)
+{
+    auto kern = x14::k_ref_spectrum14;
+    hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, x14::LDS_BYTES);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(kern, dim3(nblocks), dim3(x14::THREADS), x14::LDS_BYTES, s, rows, block_stride, twA, twB, (float4 *)refspec, xor80);
+    return hipGetLastError();
+}
+
+static hipError_t launch_xcorr_lag14(hipStream_t s, const XcorrArgs &a, int row_count, const float2 *twA, const float2 *twB)
+{
+    auto kern = x14::k_xcorr_lag14;
+    hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, x14::LDS_BYTES);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(kern, dim3(row_count, a.nblocks), dim3(x14::THREADS), x14::LDS_BYTES, s, a, twA, twB);
     return hipGetLastError();
 }
 
@@ -299,25 +338,29 @@ extern "C" int crsdr_fft(float *out, const float *in, int n, int sign, int howma
 // (ii) batched plan
 // ================================================================================================
 constexpr int kStageSlots = 4;
+constexpr int kMaxBatch = 64;
 
 struct crsdr_plan {
-    int nrows = 0, B = 0, L = 0, log2n = 0, mode = 0, device = 0, row_begin = 1, row_count = 0;
-    size_t packet_bytes = 0, matrix_off = 0;
+    int nrows = 0, B = 0, L = 0, log2n = 0, mode = 0, device = 0, row_begin = 1, row_count = 0, max_batch = 1;
+    size_t packet_bytes = 0, matrix_off = 0, packet_stride = 0, own_packet_stride = 0;
     hipStream_t own_stream = nullptr, stream = nullptr, aux = nullptr;
     hipEvent_t ev_fork = nullptr, ev_ref[2] = {nullptr, nullptr}, ev_k1done[2] = {nullptr, nullptr};
-    hipEvent_t ev_aux_done = nullptr, ev_start = nullptr, ev_stop = nullptr;
+    hipEvent_t ev_start = nullptr, ev_stop = nullptr;
     bool k1done_valid[2] = {false, false};
     int slot = 0;
-    float2 *d_tw = nullptr, *d_refspec[2] = {nullptr, nullptr};
-    int8_t *d_rows = nullptr;          // staging for host input [nrows][B]
+    float2 *d_tw = nullptr, *d_twA = nullptr, *d_twB = nullptr, *d_refspec[2] = {nullptr, nullptr}; // [T][B] each
+    int8_t *d_rows = nullptr;          // staging for host input [T][nrows][B]
     uint8_t *d_packet_alloc = nullptr; // own packet allocation (front padding for alignment)
     int8_t *d_packet_own = nullptr, *d_packet = nullptr;
-    uint32_t *d_readcnt = nullptr;
+    uint32_t *d_readcnt = nullptr;     // [T][nrows]
     uint8_t *d_mask = nullptr;
-    int32_t *d_lag = nullptr;
-    float *d_mag = nullptr, *d_frac = nullptr;
-    float2 *d_phasor = nullptr;
-    // pinned staging ring for the small per-block host arrays
+    int32_t *d_lag = nullptr, *d_lag_state = nullptr;         // [T][nrows], [nrows]
+    float *d_mag = nullptr, *d_frac = nullptr, *d_mag_state = nullptr, *d_frac_state = nullptr;
+    float2 *d_phasor = nullptr, *d_phase_state[2] = {nullptr, nullptr}; // [T][nrows], 2 x [nrows]
+    long long *d_corr = nullptr;       // [T][nrows][2]
+    int phase_cur = 0;
+    int last_nblocks = 0;
+    // pinned staging ring for the small per-batch host arrays
     uint32_t *h_readcnt = nullptr;
     uint8_t *h_mask = nullptr;
     hipEvent_t ev_stage[kStageSlots] = {};
@@ -331,22 +374,32 @@ struct crsdr_plan {
     std::vector<unsigned char> prof_has; // [slot][kernel]
 };
 
+constexpr int kProfKernels = 4;
+
 static hipEvent_t *prof_pair(crsdr_plan *p, int which)
 {
     if (!p->prof_slots) return nullptr;
     const int slot = (int)(p->prof_count % p->prof_slots);
-    p->prof_has[(size_t)slot * 3 + which] = 1;
-    return &p->prof_ev[((size_t)slot * 3 + which) * 2];
+    p->prof_has[(size_t)slot * kProfKernels + which] = 1;
+    return &p->prof_ev[((size_t)slot * kProfKernels + which) * 2];
 }
 
 static int plan_init_state(crsdr_plan *p)
 {
-    std::vector<float2> ph((size_t)p->nrows, make_float2(1.0f, 0.0f)); // src/csdrdevice.cc:39-40
-    ph[0] = make_float2(0.0f, 0.0f);                                   // pcorrection[0] is never written
-    HIP_TRY(hipMemcpy(p->d_phasor, ph.data(), sizeof(float2) * ph.size(), hipMemcpyHostToDevice));
-    HIP_TRY(hipMemset(p->d_lag, 0, sizeof(int32_t) * (size_t)p->nrows));
-    HIP_TRY(hipMemset(p->d_mag, 0, sizeof(float) * (size_t)p->nrows));
-    HIP_TRY(hipMemset(p->d_frac, 0, sizeof(float) * (size_t)p->nrows));
+    const size_t n = (size_t)p->nrows, T = (size_t)p->max_batch;
+    std::vector<float2> ph(n, make_float2(1.0f, 0.0f)); // src/csdrdevice.cc:39-40
+    ph[0] = make_float2(0.0f, 0.0f);                     // pcorrection[0] is never written
+    for (int i = 0; i < 2; ++i) HIP_TRY(hipMemcpy(p->d_phase_state[i], ph.data(), sizeof(float2) * n, hipMemcpyHostToDevice));
+    for (size_t t = 0; t < T; ++t) HIP_TRY(hipMemcpy(p->d_phasor + t * n, ph.data(), sizeof(float2) * n, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemset(p->d_lag, 0, sizeof(int32_t) * n * T));
+    HIP_TRY(hipMemset(p->d_mag, 0, sizeof(float) * n * T));
+    HIP_TRY(hipMemset(p->d_frac, 0, sizeof(float) * n * T));
+    HIP_TRY(hipMemset(p->d_lag_state, 0, sizeof(int32_t) * n));
+    HIP_TRY(hipMemset(p->d_mag_state, 0, sizeof(float) * n));
+    HIP_TRY(hipMemset(p->d_frac_state, 0, sizeof(float) * n));
+    HIP_TRY(hipMemset(p->d_corr, 0, sizeof(long long) * 2 * n * T));
+    p->phase_cur = 0;
+    p->last_nblocks = 0;
     return CRSDR_OK;
 }
 
@@ -356,29 +409,39 @@ static int plan_alloc(crsdr_plan *p)
     HIP_TRY(hipStreamCreateWithFlags(&p->own_stream, hipStreamNonBlocking));
     HIP_TRY(hipStreamCreateWithFlags(&p->aux, hipStreamNonBlocking));
     p->stream = p->own_stream;
-    hipEvent_t *evs[] = {&p->ev_fork, &p->ev_ref[0], &p->ev_ref[1], &p->ev_k1done[0], &p->ev_k1done[1], &p->ev_aux_done};
+    hipEvent_t *evs[] = {&p->ev_fork, &p->ev_ref[0], &p->ev_ref[1], &p->ev_k1done[0], &p->ev_k1done[1]};
     for (auto e : evs) HIP_TRY(hipEventCreateWithFlags(e, hipEventDisableTiming));
     for (int i = 0; i < kStageSlots; ++i) HIP_TRY(hipEventCreateWithFlags(&p->ev_stage[i], hipEventDisableTiming));
     HIP_TRY(hipEventCreate(&p->ev_start));
     HIP_TRY(hipEventCreate(&p->ev_stop));
     { int rc = make_twiddles(p->B, &p->d_tw); if (rc) return rc; }
-    const size_t rowbytes = (size_t)p->nrows * (size_t)p->B;
-    for (int i = 0; i < 2; ++i) HIP_TRY(hipMalloc((void **)&p->d_refspec[i], sizeof(float2) * (size_t)p->B));
-    HIP_TRY(hipMalloc((void **)&p->d_rows, rowbytes));
-    // own packet: pad the front so that the matrix (at +16+4N) starts 256-byte aligned
+    if (p->log2n == 14) { int rc = make_twiddles14(&p->d_twA, &p->d_twB); if (rc) return rc; }
+    const size_t n = (size_t)p->nrows, T = (size_t)p->max_batch;
+    const size_t rowbytes = n * (size_t)p->B;
+    for (int i = 0; i < 2; ++i) HIP_TRY(hipMalloc((void **)&p->d_refspec[i], sizeof(float2) * (size_t)p->B * T));
+    HIP_TRY(hipMalloc((void **)&p->d_rows, rowbytes * T));
+    // own packets: pad the front so that the matrix (at +16+4N) starts 256-byte aligned; the
+    // stride between the packets of a batch keeps that alignment
     const size_t pad = (256 - (p->matrix_off % 256)) % 256;
-    HIP_TRY(hipMalloc((void **)&p->d_packet_alloc, pad + p->packet_bytes + 256));
-    HIP_TRY(hipMemset(p->d_packet_alloc, 0, pad + p->packet_bytes + 256));
+    p->own_packet_stride = (p->packet_bytes + 255) / 256 * 256;
+    p->packet_stride = p->own_packet_stride;
+    HIP_TRY(hipMalloc((void **)&p->d_packet_alloc, pad + p->own_packet_stride * T + 256));
+    HIP_TRY(hipMemset(p->d_packet_alloc, 0, pad + p->own_packet_stride * T + 256));
     p->d_packet_own = reinterpret_cast<int8_t *>(p->d_packet_alloc + pad);
     p->d_packet = p->d_packet_own;
-    HIP_TRY(hipMalloc((void **)&p->d_readcnt, sizeof(uint32_t) * (size_t)p->nrows));
-    HIP_TRY(hipMalloc((void **)&p->d_mask, (size_t)p->nrows));
-    HIP_TRY(hipMalloc((void **)&p->d_lag, sizeof(int32_t) * (size_t)p->nrows));
-    HIP_TRY(hipMalloc((void **)&p->d_mag, sizeof(float) * (size_t)p->nrows));
-    HIP_TRY(hipMalloc((void **)&p->d_frac, sizeof(float) * (size_t)p->nrows));
-    HIP_TRY(hipMalloc((void **)&p->d_phasor, sizeof(float2) * (size_t)p->nrows));
-    HIP_TRY(hipHostMalloc((void **)&p->h_readcnt, sizeof(uint32_t) * (size_t)p->nrows * kStageSlots, hipHostMallocDefault));
-    HIP_TRY(hipHostMalloc((void **)&p->h_mask, (size_t)p->nrows * kStageSlots, hipHostMallocDefault));
+    HIP_TRY(hipMalloc((void **)&p->d_readcnt, sizeof(uint32_t) * n * T));
+    HIP_TRY(hipMalloc((void **)&p->d_mask, n));
+    HIP_TRY(hipMalloc((void **)&p->d_lag, sizeof(int32_t) * n * T));
+    HIP_TRY(hipMalloc((void **)&p->d_mag, sizeof(float) * n * T));
+    HIP_TRY(hipMalloc((void **)&p->d_frac, sizeof(float) * n * T));
+    HIP_TRY(hipMalloc((void **)&p->d_phasor, sizeof(float2) * n * T));
+    HIP_TRY(hipMalloc((void **)&p->d_corr, sizeof(long long) * 2 * n * T));
+    HIP_TRY(hipMalloc((void **)&p->d_lag_state, sizeof(int32_t) * n));
+    HIP_TRY(hipMalloc((void **)&p->d_mag_state, sizeof(float) * n));
+    HIP_TRY(hipMalloc((void **)&p->d_frac_state, sizeof(float) * n));
+    for (int i = 0; i < 2; ++i) HIP_TRY(hipMalloc((void **)&p->d_phase_state[i], sizeof(float2) * n));
+    HIP_TRY(hipHostMalloc((void **)&p->h_readcnt, sizeof(uint32_t) * n * T * kStageSlots, hipHostMallocDefault));
+    HIP_TRY(hipHostMalloc((void **)&p->h_mask, n * kStageSlots, hipHostMallocDefault));
     return plan_init_state(p);
 }
 
@@ -388,12 +451,13 @@ static void plan_free(crsdr_plan *p)
     (void)hipSetDevice(p->device);
     if (p->own_stream) (void)hipStreamSynchronize(p->own_stream);
     if (p->aux) (void)hipStreamSynchronize(p->aux);
-    void *bufs[] = {p->d_tw, p->d_refspec[0], p->d_refspec[1], p->d_rows, p->d_packet_alloc, p->d_readcnt, p->d_mask,
-                    p->d_lag, p->d_mag, p->d_frac, p->d_phasor};
+    void *bufs[] = {p->d_tw, p->d_twA, p->d_twB, p->d_refspec[0], p->d_refspec[1], p->d_rows, p->d_packet_alloc, p->d_readcnt,
+                    p->d_mask, p->d_lag, p->d_mag, p->d_frac, p->d_phasor, p->d_corr, p->d_lag_state, p->d_mag_state,
+                    p->d_frac_state, p->d_phase_state[0], p->d_phase_state[1]};
     for (void *b : bufs) if (b) (void)hipFree(b);
     if (p->h_readcnt) (void)hipHostFree(p->h_readcnt);
     if (p->h_mask) (void)hipHostFree(p->h_mask);
-    hipEvent_t evs[] = {p->ev_fork, p->ev_ref[0], p->ev_ref[1], p->ev_k1done[0], p->ev_k1done[1], p->ev_aux_done, p->ev_start, p->ev_stop};
+    hipEvent_t evs[] = {p->ev_fork, p->ev_ref[0], p->ev_ref[1], p->ev_k1done[0], p->ev_k1done[1], p->ev_start, p->ev_stop};
     for (hipEvent_t e : evs) if (e) (void)hipEventDestroy(e);
     for (int i = 0; i < kStageSlots; ++i) if (p->ev_stage[i]) (void)hipEventDestroy(p->ev_stage[i]);
     for (hipEvent_t e : p->prof_ev) if (e) (void)hipEventDestroy(e);
@@ -416,6 +480,8 @@ extern "C" int crsdr_plan_create(crsdr_plan **plan, const crsdr_plan_desc *desc)
     const int rc_rows = desc->row_count ? desc->row_count : desc->nrows - rb;
     if (rb < 1 || rc_rows < 1 || rb + rc_rows > desc->nrows)
         return fail(CRSDR_EINVAL, "plan_create: slab [%d,%d) outside signal rows [1,%d)", rb, rb + rc_rows, desc->nrows);
+    const int mb = desc->max_batch ? desc->max_batch : 1;
+    if (mb < 1 || mb > kMaxBatch) return fail(CRSDR_EINVAL, "plan_create: max_batch = %d (1..%d)", mb, kMaxBatch);
     { int rc = require_device(); if (rc) return rc; }
     int ndev = 0;
     (void)crsdr_device_count(&ndev);
@@ -424,7 +490,7 @@ extern "C" int crsdr_plan_create(crsdr_plan **plan, const crsdr_plan_desc *desc)
     crsdr_plan *p = new (std::nothrow) crsdr_plan();
     if (!p) return fail(CRSDR_ENOMEM, "plan_create: out of host memory");
     p->nrows = desc->nrows; p->B = desc->blocksize; p->L = p->B / 2; p->log2n = l2; p->mode = desc->mode;
-    p->device = desc->device; p->row_begin = rb; p->row_count = rc_rows;
+    p->device = desc->device; p->row_begin = rb; p->row_count = rc_rows; p->max_batch = mb;
     p->matrix_off = 16 + 4 * (size_t)p->nrows;
     p->packet_bytes = p->matrix_off + (size_t)p->nrows * (size_t)p->B;
     int rc = plan_alloc(p);
@@ -469,6 +535,7 @@ extern "C" int crsdr_plan_set_stream(crsdr_plan *p, void *hip_stream)
 
 extern "C" size_t crsdr_plan_packet_bytes(const crsdr_plan *p) { return p ? p->packet_bytes : 0; }
 extern "C" size_t crsdr_plan_matrix_offset(const crsdr_plan *p) { return p ? p->matrix_off : 0; }
+extern "C" size_t crsdr_plan_packet_stride(const crsdr_plan *p) { return p ? p->packet_stride : 0; }
 
 extern "C" int crsdr_plan_device_buffers(crsdr_plan *p, void **packet, void **lag, void **mag, void **frac, void **phasor)
 {
@@ -481,36 +548,47 @@ extern "C" int crsdr_plan_device_buffers(crsdr_plan *p, void **packet, void **la
     return CRSDR_OK;
 }
 
-extern "C" int crsdr_plan_bind_packet(crsdr_plan *p, void *device_packet)
+extern "C" int crsdr_plan_bind_packet(crsdr_plan *p, void *device_packet, size_t packet_stride)
 {
     if (!p) return fail(CRSDR_EINVAL, "plan_bind_packet: NULL plan");
-    if (device_packet && (((uintptr_t)device_packet + p->matrix_off) % 4) != 0)
-        return fail(CRSDR_EINVAL, "plan_bind_packet: matrix start must be 4-byte aligned");
+    if (device_packet && (((uintptr_t)device_packet + p->matrix_off) % 4 || packet_stride % 4 ||
+                          (packet_stride < p->packet_bytes && p->max_batch > 1)))
+        return fail(CRSDR_EINVAL, "plan_bind_packet: matrix start and stride must be 4-byte aligned, stride >= packet bytes");
     p->d_packet = device_packet ? (int8_t *)device_packet : p->d_packet_own;
+    p->packet_stride = device_packet ? packet_stride : p->own_packet_stride;
     return CRSDR_OK;
 }
 
-extern "C" int crsdr_plan_submit(crsdr_plan *p, const void *rows, int mem_kind, const uint32_t *readcnt,
-                                 const uint8_t *lag_mask, uint32_t seq, uint32_t flags)
+extern "C" int crsdr_plan_submit_batch(crsdr_plan *p, const void *rows, int mem_kind, int nblocks, size_t block_stride,
+                                       const uint32_t *readcnt, const uint8_t *lag_mask, uint32_t seq, uint32_t flags)
 {
     if (!p || !rows) return fail(CRSDR_EINVAL, "plan_submit: NULL plan or rows");
     if (mem_kind != CRSDR_MEM_HOST && mem_kind != CRSDR_MEM_DEVICE) return fail(CRSDR_EINVAL, "plan_submit: mem_kind = %d", mem_kind);
+    if (nblocks < 1 || nblocks > p->max_batch) return fail(CRSDR_EINVAL, "plan_submit: nblocks = %d (plan max_batch = %d)", nblocks, p->max_batch);
+    const size_t B = (size_t)p->B, n = (size_t)p->nrows, T = (size_t)nblocks;
+    if (block_stride == 0) block_stride = n * B;
+    if (block_stride < n * B) return fail(CRSDR_EINVAL, "plan_submit: block_stride smaller than one block");
     HIP_TRY(hipSetDevice(p->device));
     hipStream_t S = p->stream, A = p->aux;
-    const size_t B = (size_t)p->B;
     const uint32_t xor80 = (flags & CRSDR_OFFSET_BINARY) ? 0x80808080u : 0u;
 
     const int8_t *d_in = (const int8_t *)rows;
+    size_t d_stride = block_stride;
     bool input_ready = (flags & CRSDR_INPUT_READY) && mem_kind == CRSDR_MEM_DEVICE;
     if (mem_kind == CRSDR_MEM_HOST) {
         // reference row + this plan's slab only (cbuffer hand-off, src/crtlsdr.cc:173-203)
-        HIP_TRY(hipMemcpyAsync(p->d_rows, rows, B, hipMemcpyHostToDevice, S));
-        HIP_TRY(hipMemcpyAsync(p->d_rows + B * (size_t)p->row_begin, (const int8_t *)rows + B * (size_t)p->row_begin,
-                               B * (size_t)p->row_count, hipMemcpyHostToDevice, S));
+        for (size_t t = 0; t < T; ++t) {
+            const int8_t *src = (const int8_t *)rows + t * block_stride;
+            int8_t *dst = p->d_rows + t * n * B;
+            HIP_TRY(hipMemcpyAsync(dst, src, B, hipMemcpyHostToDevice, S));
+            HIP_TRY(hipMemcpyAsync(dst + B * (size_t)p->row_begin, src + B * (size_t)p->row_begin, B * (size_t)p->row_count,
+                                   hipMemcpyHostToDevice, S));
+        }
         d_in = p->d_rows;
+        d_stride = n * B;
     }
 
-    // small per-block host arrays through the pinned ring
+    // small per-batch host arrays through the pinned ring
     const uint32_t *d_readcnt = nullptr;
     const uint8_t *d_mask = nullptr;
     bool any_lag = !(flags & CRSDR_NO_LAG);
@@ -519,18 +597,18 @@ extern "C" int crsdr_plan_submit(crsdr_plan *p, const void *rows, int mem_kind, 
         p->stage_slot = (ss + 1) % kStageSlots;
         if (p->stage_valid[ss]) HIP_TRY(hipEventSynchronize(p->ev_stage[ss]));
         if (readcnt) {
-            uint32_t *h = p->h_readcnt + (size_t)ss * p->nrows;
-            memcpy(h, readcnt, sizeof(uint32_t) * (size_t)p->nrows);
-            HIP_TRY(hipMemcpyAsync(p->d_readcnt, h, sizeof(uint32_t) * (size_t)p->nrows, hipMemcpyHostToDevice, S));
+            uint32_t *h = p->h_readcnt + (size_t)ss * n * (size_t)p->max_batch;
+            memcpy(h, readcnt, sizeof(uint32_t) * n * T);
+            HIP_TRY(hipMemcpyAsync(p->d_readcnt, h, sizeof(uint32_t) * n * T, hipMemcpyHostToDevice, S));
             d_readcnt = p->d_readcnt;
         }
         if (lag_mask) {
-            uint8_t *h = p->h_mask + (size_t)ss * p->nrows;
-            memcpy(h, lag_mask, (size_t)p->nrows);
+            uint8_t *h = p->h_mask + (size_t)ss * n;
+            memcpy(h, lag_mask, n);
             bool any = false;
             for (int r = p->row_begin; r < p->row_begin + p->row_count; ++r) any |= (h[r] != 0);
             any_lag = any_lag && any;
-            HIP_TRY(hipMemcpyAsync(p->d_mask, h, (size_t)p->nrows, hipMemcpyHostToDevice, S));
+            HIP_TRY(hipMemcpyAsync(p->d_mask, h, n, hipMemcpyHostToDevice, S));
             d_mask = p->d_mask;
         }
         HIP_TRY(hipEventRecord(p->ev_stage[ss], S));
@@ -539,89 +617,105 @@ extern "C" int crsdr_plan_submit(crsdr_plan *p, const void *rows, int mem_kind, 
 
     if (p->prof_slots) {
         const int ps = (int)(p->prof_count % p->prof_slots);
-        for (int k = 0; k < 3; ++k) p->prof_has[(size_t)ps * 3 + k] = 0;
+        for (int k = 0; k < kProfKernels; ++k) p->prof_has[(size_t)ps * kProfKernels + k] = 0;
+        HIP_TRY(hipEventRecord(p->ev_start, S));
     }
-    HIP_TRY(hipEventRecord(p->ev_start, S));
-    HIP_TRY(hipEventRecord(p->ev_fork, S)); // everything enqueued on S so far (input copies, caller's work)
 
+    const int pin = p->phase_cur, pout = pin ^ 1;
     AlignArgs aa;
-    aa.rows = d_in; aa.packet = p->d_packet; aa.readcnt = d_readcnt; aa.lag = p->d_lag; aa.phasecorr = p->d_phasor;
-    aa.nrows = p->nrows; aa.B = p->B; aa.row_begin = p->row_begin;
+    aa.rows = d_in; aa.block_stride = d_stride; aa.packet = p->d_packet; aa.packet_stride = p->packet_stride;
+    aa.readcnt = d_readcnt; aa.lag_mask = d_mask; aa.lag = p->d_lag; aa.lag_state = p->d_lag_state; aa.corr = p->d_corr;
+    aa.phase_in = p->d_phase_state[pin]; aa.phase_out = p->d_phase_state[pout]; aa.phasor = p->d_phasor;
+    aa.nrows = p->nrows; aa.B = p->B; aa.row_begin = p->row_begin; aa.nblocks = nblocks;
     aa.digital = (p->mode == CRSDR_MODE_DIGITAL); aa.refnoise = (flags & CRSDR_REFNOISE_ENABLED) ? 1 : 0;
+    aa.xcorr_ran = any_lag ? 1 : 0;
     aa.seq = seq; aa.xor80 = xor80;
-    const dim3 k2grid((unsigned)(1 + p->row_count)), k2block(kAlignThreads);
 
     if (any_lag) {
         const int slot = (p->slot ^= 1);
-        // K0 on the aux stream: may overlap the previous block's K1 when the input is resident
-        if (!input_ready) HIP_TRY(hipStreamWaitEvent(A, p->ev_fork, 0));
+        // K0 on the aux stream: with resident input it overlaps the previous batch's K1 / K2
+        if (!input_ready) {
+            HIP_TRY(hipEventRecord(p->ev_fork, S)); // input copies / the caller's producer work
+            HIP_TRY(hipStreamWaitEvent(A, p->ev_fork, 0));
+        }
         if (p->k1done_valid[slot]) HIP_TRY(hipStreamWaitEvent(A, p->ev_k1done[slot], 0)); // refspec[slot] free again
         hipEvent_t *pe0 = prof_pair(p, CRSDR_KERNEL_REF_SPECTRUM);
         if (pe0) HIP_TRY(hipEventRecord(pe0[0], A));
-        HIP_TRY(CRSDR_DISPATCH_LOG2(p->log2n, (launch_ref_spectrum<LG>(A, d_in, p->d_tw, p->d_refspec[slot], xor80))));
+        if (p->log2n == 14) HIP_TRY(launch_ref_spectrum14(A, nblocks, d_in, d_stride, p->d_twA, p->d_twB, p->d_refspec[slot], xor80));
+        else HIP_TRY(CRSDR_DISPATCH_LOG2(p->log2n, (launch_ref_spectrum<LG>(A, nblocks, d_in, d_stride, p->d_tw, p->d_refspec[slot], xor80))));
         if (pe0) HIP_TRY(hipEventRecord(pe0[1], A));
         HIP_TRY(hipEventRecord(p->ev_ref[slot], A));
-        if (!aa.digital) {
-            // faithful: the phase path does not depend on this block's lags (src/ccoherent.cc:271-278
-            // run before computelag :284) -> K2 on the aux stream, concurrent with K1
-            if (input_ready) HIP_TRY(hipStreamWaitEvent(A, p->ev_fork, 0)); // packet buffer ordering
-            hipEvent_t *pe2 = prof_pair(p, CRSDR_KERNEL_ALIGN_QUANT);
-            if (pe2) HIP_TRY(hipEventRecord(pe2[0], A));
-            hipLaunchKernelGGL(k_align_quant, k2grid, k2block, 0, A, aa);
-            HIP_TRY(hipGetLastError());
-            if (pe2) HIP_TRY(hipEventRecord(pe2[1], A));
-            HIP_TRY(hipEventRecord(p->ev_aux_done, A));
-        }
+
+        XcorrArgs xa;
+        xa.rows = d_in; xa.block_stride = d_stride; xa.refspec = p->d_refspec[slot]; xa.lag_mask = d_mask;
+        xa.row_begin = p->row_begin; xa.nrows = p->nrows; xa.nblocks = nblocks; xa.xor80 = xor80;
+        xa.lag = p->d_lag; xa.mag = p->d_mag; xa.frac = p->d_frac;
+        xa.lag_state = p->d_lag_state; xa.mag_state = p->d_mag_state; xa.frac_state = p->d_frac_state;
         HIP_TRY(hipStreamWaitEvent(S, p->ev_ref[slot], 0));
         hipEvent_t *pe1 = prof_pair(p, CRSDR_KERNEL_XCORR_LAG);
         if (pe1) HIP_TRY(hipEventRecord(pe1[0], S));
-        HIP_TRY(CRSDR_DISPATCH_LOG2(p->log2n, (launch_xcorr_lag<LG>(S, p->row_count, d_in, p->d_tw, p->d_refspec[slot], d_mask,
-                                                                    p->row_begin, xor80, p->d_lag, p->d_mag, p->d_frac))));
+        if (p->log2n == 14) HIP_TRY(launch_xcorr_lag14(S, xa, p->row_count, p->d_twA, p->d_twB));
+        else HIP_TRY(CRSDR_DISPATCH_LOG2(p->log2n, (launch_xcorr_lag<LG>(S, xa, p->row_count, p->d_tw))));
         if (pe1) HIP_TRY(hipEventRecord(pe1[1], S));
         HIP_TRY(hipEventRecord(p->ev_k1done[slot], S));
         p->k1done_valid[slot] = true;
-        if (aa.digital) {
-            hipEvent_t *pe2 = prof_pair(p, CRSDR_KERNEL_ALIGN_QUANT);
-            if (pe2) HIP_TRY(hipEventRecord(pe2[0], S));
-            hipLaunchKernelGGL(k_align_quant, k2grid, k2block, 0, S, aa);
-            HIP_TRY(hipGetLastError());
-            if (pe2) HIP_TRY(hipEventRecord(pe2[1], S));
-        } else {
-            HIP_TRY(hipStreamWaitEvent(S, p->ev_aux_done, 0)); // join
-        }
-    } else {
-        // "locked" steady state: no row requests a lag -> phase path only (src/ccoherent.cc:284 skipped)
-        hipEvent_t *pe2 = prof_pair(p, CRSDR_KERNEL_ALIGN_QUANT);
-        if (pe2) HIP_TRY(hipEventRecord(pe2[0], S));
-        hipLaunchKernelGGL(k_align_quant, k2grid, k2block, 0, S, aa);
-        HIP_TRY(hipGetLastError());
-        if (pe2) HIP_TRY(hipEventRecord(pe2[1], S));
     }
-    HIP_TRY(hipEventRecord(p->ev_stop, S));
+    // phase path: faithful mode does not depend on this batch's lags, digital mode does; either
+    // way it follows K1 on the main stream (K1 is VALU bound, these two are the HBM-bound tail)
+    if (aa.refnoise) {
+        hipEvent_t *pe = prof_pair(p, CRSDR_KERNEL_PHASE_DOT);
+        if (pe) HIP_TRY(hipEventRecord(pe[0], S));
+        hipLaunchKernelGGL(k_phase_dot, dim3(p->row_count, nblocks), dim3(kAlignThreads), 0, S, aa);
+        HIP_TRY(hipGetLastError());
+        if (pe) HIP_TRY(hipEventRecord(pe[1], S));
+    }
+    {
+        hipEvent_t *pe = prof_pair(p, CRSDR_KERNEL_ALIGN_QUANT);
+        if (pe) HIP_TRY(hipEventRecord(pe[0], S));
+        hipLaunchKernelGGL(k_align_quant, dim3(1 + p->row_count, nblocks), dim3(kAlignThreads), 0, S, aa);
+        HIP_TRY(hipGetLastError());
+        if (pe) HIP_TRY(hipEventRecord(pe[1], S));
+    }
+    p->phase_cur = pout;
+    p->last_nblocks = nblocks;
+    if (p->prof_slots) { HIP_TRY(hipEventRecord(p->ev_stop, S)); p->prof_count++; }
     p->submitted = true;
-    if (p->prof_slots) p->prof_count++;
+    return CRSDR_OK;
+}
+
+extern "C" int crsdr_plan_submit(crsdr_plan *p, const void *rows, int mem_kind, const uint32_t *readcnt,
+                                 const uint8_t *lag_mask, uint32_t seq, uint32_t flags)
+{
+    return crsdr_plan_submit_batch(p, rows, mem_kind, 1, 0, readcnt, lag_mask, seq, flags);
+}
+
+extern "C" int crsdr_plan_fetch_block(crsdr_plan *p, int block, int32_t *lag, float *mag, float *frac, float *phasor,
+                                      int8_t *packet)
+{
+    if (!p) return fail(CRSDR_EINVAL, "plan_fetch: NULL plan");
+    if (!p->submitted) return fail(CRSDR_ESTATE, "plan_fetch: nothing submitted");
+    if (block < 0) block = p->last_nblocks - 1;
+    if (block >= p->last_nblocks) return fail(CRSDR_EINVAL, "plan_fetch: block %d of a batch of %d", block, p->last_nblocks);
+    HIP_TRY(hipSetDevice(p->device));
+    HIP_TRY(hipStreamSynchronize(p->stream));
+    const size_t n = (size_t)p->nrows, o = (size_t)block * n;
+    if (lag) HIP_TRY(hipMemcpy(lag, p->d_lag + o, sizeof(int32_t) * n, hipMemcpyDeviceToHost));
+    if (mag) HIP_TRY(hipMemcpy(mag, p->d_mag + o, sizeof(float) * n, hipMemcpyDeviceToHost));
+    if (frac) HIP_TRY(hipMemcpy(frac, p->d_frac + o, sizeof(float) * n, hipMemcpyDeviceToHost));
+    if (phasor) HIP_TRY(hipMemcpy(phasor, p->d_phasor + o, sizeof(float2) * n, hipMemcpyDeviceToHost));
+    if (packet) HIP_TRY(hipMemcpy(packet, p->d_packet + (size_t)block * p->packet_stride, p->packet_bytes, hipMemcpyDeviceToHost));
     return CRSDR_OK;
 }
 
 extern "C" int crsdr_plan_fetch(crsdr_plan *p, int32_t *lag, float *mag, float *frac, float *phasor, int8_t *packet)
 {
-    if (!p) return fail(CRSDR_EINVAL, "plan_fetch: NULL plan");
-    if (!p->submitted) return fail(CRSDR_ESTATE, "plan_fetch: nothing submitted");
-    HIP_TRY(hipSetDevice(p->device));
-    HIP_TRY(hipStreamSynchronize(p->stream));
-    const size_t n = (size_t)p->nrows;
-    if (lag) HIP_TRY(hipMemcpy(lag, p->d_lag, sizeof(int32_t) * n, hipMemcpyDeviceToHost));
-    if (mag) HIP_TRY(hipMemcpy(mag, p->d_mag, sizeof(float) * n, hipMemcpyDeviceToHost));
-    if (frac) HIP_TRY(hipMemcpy(frac, p->d_frac, sizeof(float) * n, hipMemcpyDeviceToHost));
-    if (phasor) HIP_TRY(hipMemcpy(phasor, p->d_phasor, sizeof(float2) * n, hipMemcpyDeviceToHost));
-    if (packet) HIP_TRY(hipMemcpy(packet, p->d_packet, p->packet_bytes, hipMemcpyDeviceToHost));
-    return CRSDR_OK;
+    return crsdr_plan_fetch_block(p, -1, lag, mag, frac, phasor, packet);
 }
 
 extern "C" int crsdr_plan_last_elapsed_ms(crsdr_plan *p, float *ms)
 {
     if (!p || !ms) return fail(CRSDR_EINVAL, "plan_last_elapsed_ms: NULL argument");
-    if (!p->submitted) return fail(CRSDR_ESTATE, "plan_last_elapsed_ms: nothing submitted");
+    if (!p->submitted || !p->prof_slots) return fail(CRSDR_ESTATE, "plan_last_elapsed_ms: enable profiling and submit first");
     HIP_TRY(hipSetDevice(p->device));
     HIP_TRY(hipEventSynchronize(p->ev_stop));
     HIP_TRY(hipEventElapsedTime(ms, p->ev_start, p->ev_stop));
@@ -637,8 +731,8 @@ extern "C" int crsdr_plan_enable_profiling(crsdr_plan *p, int slots)
     p->prof_ev.clear(); p->prof_has.clear();
     p->prof_slots = 0; p->prof_count = 0;
     if (slots == 0) return CRSDR_OK;
-    p->prof_ev.assign((size_t)slots * 6, nullptr);
-    p->prof_has.assign((size_t)slots * 3, 0);
+    p->prof_ev.assign((size_t)slots * kProfKernels * 2, nullptr);
+    p->prof_has.assign((size_t)slots * kProfKernels, 0);
     for (auto &e : p->prof_ev) HIP_TRY(hipEventCreate(&e));
     p->prof_slots = slots;
     return CRSDR_OK;
@@ -646,17 +740,17 @@ extern "C" int crsdr_plan_enable_profiling(crsdr_plan *p, int slots)
 
 extern "C" int crsdr_plan_kernel_times(crsdr_plan *p, int which, float *ms, int capacity, int *count)
 {
-    if (!p || !ms || !count || which < 0 || which > 2 || capacity < 0) return fail(CRSDR_EINVAL, "plan_kernel_times: bad argument");
+    if (!p || !ms || !count || which < 0 || which >= kProfKernels || capacity < 0) return fail(CRSDR_EINVAL, "plan_kernel_times: bad argument");
     *count = 0;
     if (!p->prof_slots) return fail(CRSDR_ESTATE, "plan_kernel_times: profiling not enabled");
     int rc = crsdr_plan_sync(p);
     if (rc) return rc;
-    const long n = p->prof_count < p->prof_slots ? p->prof_count : p->prof_slots;
-    const long first = p->prof_count - n;
+    const long nrec = p->prof_count < p->prof_slots ? p->prof_count : p->prof_slots;
+    const long first = p->prof_count - nrec;
     for (long i = first; i < p->prof_count && *count < capacity; ++i) {
         const int slot = (int)(i % p->prof_slots);
-        if (!p->prof_has[(size_t)slot * 3 + which]) continue;
-        hipEvent_t *pe = &p->prof_ev[((size_t)slot * 3 + which) * 2];
+        if (!p->prof_has[(size_t)slot * kProfKernels + which]) continue;
+        hipEvent_t *pe = &p->prof_ev[((size_t)slot * kProfKernels + which) * 2];
         float t = 0.f;
         HIP_TRY(hipEventElapsedTime(&t, pe[0], pe[1]));
         ms[(*count)++] = t;

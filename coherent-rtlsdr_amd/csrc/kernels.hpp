@@ -7,40 +7,24 @@
 //                       int8 -> pad at [0,L) -> DIF FFT -> x conj(ref spectrum) -> DIT inverse
 //                       FFT -> |.|^2 -> workgroup argmax (first maximum) -> lag, mag, frac
 //                       (src/crtlsdr.cc:205-207, src/ccoherent.cc:123-142,174-234)
-//   k_align_quant   K2  one workgroup per row: exact integer conjugate dot product against
-//                       the ref row -> unit phasor -> EMA -> rotate (+ integer shift in
-//                       digital mode) -> x127, saturate, round-half-even -> int8 row at its
-//                       packet offset (src/csdrdevice.cc:58-84, src/cpacketizer.cc:137-172)
+//   k_phase_dot     K2a one workgroup per (row, block): exact integer conjugate dot product of
+//                       the (shifted) row against the ref row (src/csdrdevice.cc:62)
+//   k_align_quant   K2b one workgroup per (row, block): unit phasor -> EMA chain over the
+//                       batch -> rotate (+ integer shift in digital mode) -> x127, saturate,
+//                       round-half-even -> int8 row at its packet offset
+//                       (src/csdrdevice.cc:63-84, src/cpacketizer.cc:137-172)
+// Every kernel takes a batch of T consecutive blocks (grid.y = block index inside the batch):
+// the host cost of a submit and the launch gaps are paid once per batch, and a GPU that owns
+// only a slab of the rows still gets T x rows workgroups to fill its 256 CUs.
 //   k_op_*              single-op kernels behind the per-op C ABI (class cdsp)
 #pragma once
+#include "arith.hpp"
 #include "fft_lds.hpp"
+#include "plan_args.hpp"
+#include "xcorr14.hpp"
 #include <stdint.h>
 
 namespace crsdr {
-
-// ---- bit-parity arithmetic helpers (no FMA contraction: one rounding per op, oracle order) --
-
-// cdsp::convtofloat src/cdsp.cc:41-44: (float)x * (1.0f/127.0f)
-__device__ __forceinline__ float i8_to_f32(int x) { return __fmul_rn((float)x, 1.0f / 127.0f); }
-
-// cdsp::convto8bit src/cdsp.cc:51-54: r = x*127; clamp [-128,127]; rintf (half-even); NaN -> 0
-__device__ __forceinline__ int f32_to_i8(float x)
-{
-    float r = __fmul_rn(x, 127.0f);
-    if (r > 127.0f) return 127;
-    if (r < -128.0f) return -128;
-    if (r != r) return 0;
-    return (int)rintf(r);
-}
-
-// cdsp::scalarmul src/cdsp.cc:46-49: (ar*sr - ai*si) + j(ar*si + ai*sr), each op rounded once
-__device__ __forceinline__ float2 rot_rn(float2 a, float2 s)
-{
-    return make_float2(__fsub_rn(__fmul_rn(a.x, s.x), __fmul_rn(a.y, s.y)),
-                       __fadd_rn(__fmul_rn(a.x, s.y), __fmul_rn(a.y, s.x)));
-}
-
-__device__ __forceinline__ int sext8(uint32_t w, int byte) { return (int)(int8_t)((w >> (8 * byte)) & 0xFFu); }
 
 // ---- row load: int8 IQ row -> complex fp32 in LDS with the reference's zero-pad placement ----
 // signal rows: samples in A[0..L), zeros in A[L..2L)   (crtlsdr::convtofloat  src/crtlsdr.cc:205-207)
@@ -68,12 +52,15 @@ __device__ __forceinline__ void load_row_to_lds(float2 *A, const int8_t *__restr
 // ---- K0 ---------------------------------------------------------------------------------------
 template <int LOG2N>
 __global__ __launch_bounds__(FftGeom<LOG2N>::THREADS) void k_ref_spectrum(
-    const int8_t *__restrict__ ref_row, const float2 *__restrict__ tw, float2 *__restrict__ refspec, uint32_t xor80)
+    const int8_t *__restrict__ rows, size_t block_stride, const float2 *__restrict__ tw, float2 *__restrict__ refspec_base,
+    uint32_t xor80)
 {
     using G = FftGeom<LOG2N>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float2 *A = reinterpret_cast<float2 *>(smem);
     const int tid = threadIdx.x;
+    const int8_t *ref_row = rows + (size_t)blockIdx.x * block_stride; // row 0 of block blockIdx.x
+    float2 *refspec = refspec_base + (size_t)blockIdx.x * G::N;
     load_row_to_lds<LOG2N>(A, ref_row, true, xor80, tid);
     __syncthreads();
     fft_dif_range<LOG2N, -1, 0, G::NPASS>(A, tw, tid);
@@ -96,10 +83,7 @@ __device__ __forceinline__ void argmax_take(ArgMax &a, float m, int idx)
 }
 
 template <int LOG2N>
-__global__ __launch_bounds__(FftGeom<LOG2N>::THREADS) void k_xcorr_lag(
-    const int8_t *__restrict__ rows, const float2 *__restrict__ tw, const float2 *__restrict__ refspec,
-    const uint8_t *__restrict__ lag_mask, int row_begin, uint32_t xor80,
-    int32_t *__restrict__ lag, float *__restrict__ mag, float *__restrict__ frac)
+__global__ __launch_bounds__(FftGeom<LOG2N>::THREADS) void k_xcorr_lag(XcorrArgs a, const float2 *__restrict__ tw)
 {
     using G = FftGeom<LOG2N>;
     constexpr int N = G::N, L = N / 2, NP = G::NPASS;
@@ -107,10 +91,11 @@ __global__ __launch_bounds__(FftGeom<LOG2N>::THREADS) void k_xcorr_lag(
     float2 *A = reinterpret_cast<float2 *>(smem);
     ArgMax *wred = reinterpret_cast<ArgMax *>(smem + sizeof(float2) * N);
     const int tid = threadIdx.x;
-    const int row = row_begin + blockIdx.x;
-    if (lag_mask && !lag_mask[row]) return; // not requested this block: lag/mag keep their value
+    const int row = a.row_begin + blockIdx.x, t = blockIdx.y;
+    if (xcorr_skip(a, row, t, tid)) return; // not requested this batch: lag/mag keep their value
+    const float2 *__restrict__ refspec = a.refspec + (size_t)t * N;
 
-    load_row_to_lds<LOG2N>(A, rows + (size_t)row * N, false, xor80, tid);
+    load_row_to_lds<LOG2N>(A, a.rows + (size_t)t * a.block_stride + (size_t)row * N, false, a.xor80, tid);
     __syncthreads();
     // forward passes 0 .. NP-2 (each followed by a barrier)
     fft_dif_range<LOG2N, -1, 0, NP - 1>(A, tw, tid);
@@ -183,133 +168,136 @@ __global__ __launch_bounds__(FftGeom<LOG2N>::THREADS) void k_xcorr_lag(
             float den = (ym - 2.0f * b.m) + yp;
             if (den != 0.0f) D = (0.5f * (ym - yp)) / den;
         }
-        lag[row] = idx - L;                       // src/ccoherent.cc:232
-        mag[row] = sqrtf(b.m / (float)L);         // src/ccoherent.cc:204
-        frac[row] = D;
+        xcorr_publish(a, row, t, idx - L /* src/ccoherent.cc:232 */, sqrtf(b.m / (float)L) /* :204 */, D);
     }
 }
 
-// ---- K2 ---------------------------------------------------------------------------------------
-// grid.x = 1 + owned signal rows; block 0 copies the raw reference row (cpacketize::write(int8*)
-// src/cpacketizer.cc:137-156) and writes the header; block b >= 1 handles row row_begin + b - 1.
-struct AlignArgs {
-    const int8_t *rows;      // [nrows][B]
-    int8_t *packet;          // hdr + readcnt + matrix
-    const uint32_t *readcnt; // device [nrows] or nullptr (use seq)
-    const int32_t *lag;      // device [nrows]
-    float2 *phasecorr;       // device [nrows]  csdrdevice::phasecorr (== phasecorrprev after a block)
-    int nrows, B, row_begin;
-    int digital, refnoise;
-    uint32_t seq, xor80;
-};
-
+// ---- K2a / K2b ------------------------------------------------------------------------------------
 constexpr int kAlignThreads = 256;
 
-__global__ __launch_bounds__(kAlignThreads) void k_align_quant(AlignArgs a)
+// lag (in samples) the digital mode shifts `row` of batch block t by
+__device__ __forceinline__ int align_shift(const AlignArgs &a, int row, int t)
+{
+    if (!a.digital) return 0;
+    const bool requested = a.xcorr_ran && (!a.lag_mask || a.lag_mask[row]);
+    return requested ? a.lag[(size_t)t * a.nrows + row] : a.lag_state[row];
+}
+
+// one 32-bit word = samples (2i, 2i+1) of the row shifted by d: y[n] = s[n + d], zero outside [0,L)
+__device__ __forceinline__ uint32_t shifted_word(const uint32_t *__restrict__ s32, int i, int d, int L, uint32_t xor80)
+{
+    const int m0 = 2 * i + d;                 // source sample of the low half
+    const int j = m0 >> 1;                    // floor: source word of sample m0 (m0 even) or m0-1 (odd)
+    const int nw = L >> 1;
+    uint32_t w;
+    if (m0 & 1) {
+        const uint32_t lo = ((unsigned)j < (unsigned)nw) ? (s32[j] ^ xor80) : 0u;
+        const uint32_t hi = ((unsigned)(j + 1) < (unsigned)nw) ? (s32[j + 1] ^ xor80) : 0u;
+        w = (lo >> 16) | (hi << 16);
+    } else {
+        w = ((unsigned)j < (unsigned)nw) ? (s32[j] ^ xor80) : 0u;
+    }
+    return w; // out-of-range samples are exactly the zero-filled words / halves
+}
+
+// K2a: corr[t][row] = sum_n y[n] conj(r[n]) in exact integer arithmetic.  int8 products summed
+// exactly (|sum| <= 2^15 L): the fp32 value csdrdevice::est_phasecorrect (src/csdrdevice.cc:62)
+// accumulates is a rounding of this, scaled by 1/127^2 -- and the phasor is scale-invariant.
+__global__ __launch_bounds__(kAlignThreads) void k_phase_dot(AlignArgs a)
 {
     __shared__ long long sred[2 * (kAlignThreads / 64)];
+    const int tid = threadIdx.x, t = blockIdx.y;
+    const int row = a.row_begin + (int)blockIdx.x;
+    const int B = a.B, L = B >> 1;
+    const int8_t *blk = a.rows + (size_t)t * a.block_stride;
+    const uint32_t *s32 = reinterpret_cast<const uint32_t *>(blk + (size_t)row * B);
+    const uint32_t *r32 = reinterpret_cast<const uint32_t *>(blk);
+    const int d = align_shift(a, row, t);
+    // bytes of a word: [I0 Q0 I1 Q1]; int32 partials are safe (<= 2^16 per word, <= 2^13 words per thread)
+    int re = 0, im = 0;
+    for (int i = tid; i < B / 4; i += kAlignThreads) {
+        const uint32_t s = (d == 0) ? (s32[i] ^ a.xor80) : shifted_word(s32, i, d, L, a.xor80);
+        const uint32_t r = r32[i] ^ a.xor80;
+        const uint32_t sw = ((s >> 8) & 0x00FF00FFu) | ((s << 8) & 0xFF00FF00u);     // [Q0 I0 Q1 I1]
+        re = __builtin_amdgcn_sdot4((int)s, (int)r, re, false);                       // I.rI + Q.rQ
+        im = __builtin_amdgcn_sdot4((int)sw, (int)(r & 0x00FF00FFu), im, false);      // + Q.rI
+        im -= __builtin_amdgcn_sdot4((int)sw, (int)(r & 0xFF00FF00u), 0, false);      // - I.rQ
+    }
+    long long acc_re = re, acc_im = im;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        acc_re += __shfl_xor(acc_re, off, 64);
+        acc_im += __shfl_xor(acc_im, off, 64);
+    }
+    if ((tid & 63) == 0) { sred[2 * (tid >> 6)] = acc_re; sred[2 * (tid >> 6) + 1] = acc_im; }
+    __syncthreads();
+    if (tid == 0) {
+        long long sr = 0, si = 0;
+        for (int w = 0; w < kAlignThreads / 64; ++w) { sr += sred[2 * w]; si += sred[2 * w + 1]; }
+        a.corr[2 * ((size_t)t * a.nrows + row)] = sr;
+        a.corr[2 * ((size_t)t * a.nrows + row) + 1] = si;
+    }
+}
+
+// K2b: grid.x = 1 + owned signal rows; block x = 0 writes the packet header and copies the raw
+// reference row (cpacketize::write(int8*) src/cpacketizer.cc:137-156); block x >= 1 handles row
+// row_begin + x - 1 of batch block t = blockIdx.y.
+__global__ __launch_bounds__(kAlignThreads) void k_align_quant(AlignArgs a)
+{
     __shared__ float2 sp;
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, t = blockIdx.y;
     const int B = a.B, L = B >> 1;
     const size_t moff = 16 + 4 * (size_t)a.nrows;
+    const int8_t *blk = a.rows + (size_t)t * a.block_stride;
+    int8_t *packet = a.packet + (size_t)t * a.packet_stride;
     if (blockIdx.x == 0) {
         // header hdr0{globalseqn,N,L,unused} src/cpacketizer.cc:112-116 and readcnt words :142,163
-        uint32_t *h = reinterpret_cast<uint32_t *>(a.packet);
-        if (tid == 0) { h[0] = a.seq; h[1] = (uint32_t)a.nrows; h[2] = (uint32_t)L; h[3] = 0u; }
-        for (int r = tid; r < a.nrows; r += kAlignThreads) h[4 + r] = a.readcnt ? a.readcnt[r] : a.seq;
-        const uint32_t *src = reinterpret_cast<const uint32_t *>(a.rows);
-        uint32_t *dst = reinterpret_cast<uint32_t *>(a.packet + moff);
+        uint32_t *h = reinterpret_cast<uint32_t *>(packet);
+        const uint32_t seq = a.seq + (uint32_t)t;
+        if (tid == 0) { h[0] = seq; h[1] = (uint32_t)a.nrows; h[2] = (uint32_t)L; h[3] = 0u; }
+        for (int r = tid; r < a.nrows; r += kAlignThreads) h[4 + r] = a.readcnt ? a.readcnt[(size_t)t * a.nrows + r] : seq;
+        const uint32_t *src = reinterpret_cast<const uint32_t *>(blk);
+        uint32_t *dst = reinterpret_cast<uint32_t *>(packet + moff);
         for (int i = tid; i < B / 4; i += kAlignThreads) dst[i] = src[i] ^ a.xor80;
         return;
     }
     const int row = a.row_begin + (int)blockIdx.x - 1;
-    const uint32_t *s32 = reinterpret_cast<const uint32_t *>(a.rows + (size_t)row * B);
-    const uint32_t *r32 = reinterpret_cast<const uint32_t *>(a.rows);
-    const int16_t *s16 = reinterpret_cast<const int16_t *>(a.rows + (size_t)row * B);
-    const int d = a.digital ? a.lag[row] : 0;
-    float2 p = a.phasecorr[row];
+    const uint32_t *s32 = reinterpret_cast<const uint32_t *>(blk + (size_t)row * B);
+    const int d = align_shift(a, row, t);
 
-    if (a.refnoise) {
-        // corr = sum_n y[n] conj(r[n]) with y[n] = s[n + d]; int8 products summed exactly in
-        // integers (|sum| <= 2^15 L): the fp32 value csdrdevice::est_phasecorrect
-        // (src/csdrdevice.cc:62) accumulates is a rounding of this, scaled by 1/127^2.
-        long long acc_re = 0, acc_im = 0;
-        if (d == 0) {
-            // two complex samples per 32-bit word: bytes [I0 Q0 I1 Q1]; int32 partials are safe
-            // (|term| <= 2^16 per word, <= 2^15 words per thread)
-            int re = 0, im = 0;
-            for (int i = tid; i < B / 4; i += kAlignThreads) {
-                uint32_t s = s32[i] ^ a.xor80, r = r32[i] ^ a.xor80;
-                uint32_t sw = ((s >> 8) & 0x00FF00FFu) | ((s << 8) & 0xFF00FF00u); // [Q0 I0 Q1 I1]
-                re = __builtin_amdgcn_sdot4((int)s, (int)r, re, false);               // I.I + Q.Q
-                im = __builtin_amdgcn_sdot4((int)sw, (int)(r & 0x00FF00FFu), im, false); // + Q.rI
-                im -= __builtin_amdgcn_sdot4((int)sw, (int)(r & 0xFF00FF00u), 0, false); // - I.rQ
-            }
-            acc_re += re; acc_im += im;
-        } else {
-            const int lo = d < 0 ? -d : 0, hi = d > 0 ? L - d : L; // overlap of shifted row and ref
-            const int16_t *r16 = reinterpret_cast<const int16_t *>(a.rows);
-            const uint32_t x16 = a.xor80 & 0xFFFFu;
-            for (int n = lo + tid; n < hi; n += kAlignThreads) {
-                uint32_t s = (uint16_t)s16[n + d] ^ x16, r = (uint16_t)r16[n] ^ x16;
-                int si = sext8(s, 0), sq = sext8(s, 1), ri = sext8(r, 0), rq = sext8(r, 1);
-                acc_re += si * ri + sq * rq;
-                acc_im += sq * ri - si * rq;
+    if (tid == 0) {
+        // csdrdevice::est_phasecorrect (src/csdrdevice.cc:58-69) for blocks 0..t of this batch:
+        //   phasecorr = conj(corr)/|corr| (:63);  phasecorr = 0.5 phasecorr + 0.5 phasecorrprev (:66-67)
+        // |corr| == 0 holds the previous phasor (defined policy; the reference would go NaN for ever).
+        float2 p = a.phase_in[row];
+        if (a.refnoise) {
+            for (int u = 0; u <= t; ++u) {
+                const long long sr = a.corr[2 * ((size_t)u * a.nrows + row)], si = a.corr[2 * ((size_t)u * a.nrows + row) + 1];
+                if (sr != 0 || si != 0) {
+                    const double cr = (double)sr, ci = (double)si;
+                    const double inv = 1.0 / sqrt(cr * cr + ci * ci);
+                    const float pr = (float)(cr * inv), pi = (float)(-ci * inv);
+                    p = make_float2(__fadd_rn(__fmul_rn(0.5f, pr), __fmul_rn(0.5f, p.x)),
+                                    __fadd_rn(__fmul_rn(0.5f, pi), __fmul_rn(0.5f, p.y)));
+                }
             }
         }
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) {
-            acc_re += __shfl_xor(acc_re, off, 64);
-            acc_im += __shfl_xor(acc_im, off, 64);
-        }
-        if ((tid & 63) == 0) { sred[2 * (tid >> 6)] = acc_re; sred[2 * (tid >> 6) + 1] = acc_im; }
-        __syncthreads();
-        if (tid == 0) {
-            long long sr = 0, si = 0;
-            for (int w = 0; w < kAlignThreads / 64; ++w) { sr += sred[2 * w]; si += sred[2 * w + 1]; }
-            if (sr != 0 || si != 0) {
-                // phasecorr = conj(corr)/|corr| (src/csdrdevice.cc:63), then the alpha = 0.5 EMA
-                // (:66-67).  |corr| == 0 holds the previous phasor (defined policy; the
-                // reference would go NaN for ever).
-                double cr = (double)sr, ci = (double)si;
-                double inv = 1.0 / sqrt(cr * cr + ci * ci);
-                float pr = (float)(cr * inv), pi = (float)(-ci * inv);
-                p = make_float2(__fadd_rn(__fmul_rn(0.5f, pr), __fmul_rn(0.5f, p.x)),
-                                __fadd_rn(__fmul_rn(0.5f, pi), __fmul_rn(0.5f, p.y)));
-                a.phasecorr[row] = p;
-            }
-            sp = p;
-        }
-        __syncthreads();
-        p = sp;
+        a.phasor[(size_t)t * a.nrows + row] = p;       // get_phasecorrect() after block t
+        if (t == a.nblocks - 1) a.phase_out[row] = p;  // state carried to the next batch
+        sp = p;
     }
+    __syncthreads();
+    const float2 p = sp;
 
     // csdrdevice::phasecorrect (src/csdrdevice.cc:80-84) + cpacketize::write(complex<float>*)
-    // (src/cpacketizer.cc:158-172): y * p, x127, saturate, round-half-even, int8 at row offset
-    int8_t *out = a.packet + moff + (size_t)row * B;
-    if (d == 0) {
-        uint32_t *o32 = reinterpret_cast<uint32_t *>(out);
-        for (int i = tid; i < B / 4; i += kAlignThreads) {
-            uint32_t s = s32[i] ^ a.xor80;
-            float2 y0 = rot_rn(make_float2(i8_to_f32(sext8(s, 0)), i8_to_f32(sext8(s, 1))), p);
-            float2 y1 = rot_rn(make_float2(i8_to_f32(sext8(s, 2)), i8_to_f32(sext8(s, 3))), p);
-            uint32_t w = (uint32_t)(f32_to_i8(y0.x) & 0xFF) | ((uint32_t)(f32_to_i8(y0.y) & 0xFF) << 8) |
-                         ((uint32_t)(f32_to_i8(y1.x) & 0xFF) << 16) | ((uint32_t)(f32_to_i8(y1.y) & 0xFF) << 24);
-            o32[i] = w;
-        }
-    } else {
-        uint16_t *o16 = reinterpret_cast<uint16_t *>(out);
-        const uint32_t x16 = a.xor80 & 0xFFFFu;
-        for (int n = tid; n < L; n += kAlignThreads) {
-            const int m = n + d;
-            uint32_t w = 0;
-            if (m >= 0 && m < L) {
-                uint32_t s = (uint16_t)s16[m] ^ x16;
-                float2 y = rot_rn(make_float2(i8_to_f32(sext8(s, 0)), i8_to_f32(sext8(s, 1))), p);
-                w = (uint32_t)(f32_to_i8(y.x) & 0xFF) | ((uint32_t)(f32_to_i8(y.y) & 0xFF) << 8);
-            }
-            o16[n] = (uint16_t)w;
-        }
+    // (src/cpacketizer.cc:158-172): y * p, x127, saturate, round-half-even, int8 at the row offset
+    uint32_t *o32 = reinterpret_cast<uint32_t *>(packet + moff + (size_t)row * B);
+    for (int i = tid; i < B / 4; i += kAlignThreads) {
+        const uint32_t s = (d == 0) ? (s32[i] ^ a.xor80) : shifted_word(s32, i, d, L, a.xor80);
+        const float2 y0 = rot_rn(make_float2(i8_to_f32(sext8(s, 0)), i8_to_f32(sext8(s, 1))), p);
+        const float2 y1 = rot_rn(make_float2(i8_to_f32(sext8(s, 2)), i8_to_f32(sext8(s, 3))), p);
+        o32[i] = (uint32_t)(f32_to_i8(y0.x) & 0xFF) | ((uint32_t)(f32_to_i8(y0.y) & 0xFF) << 8) |
+                 ((uint32_t)(f32_to_i8(y1.x) & 0xFF) << 16) | ((uint32_t)(f32_to_i8(y1.y) & 0xFF) << 24);
     }
 }
 

@@ -1,0 +1,68 @@
+// plan_args.hpp -- kernel argument blocks of the batched plan (plain structs passed by value).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace crsdr {
+
+// K1 (cross-correlation): grid = (owned signal rows, T blocks)
+struct XcorrArgs {
+    const int8_t *rows;     // batch base: block t at rows + t*block_stride, layout [nrows][B]
+    size_t block_stride;    // bytes
+    const float2 *refspec;  // [T][B] conj reference spectra of this batch (kernel-specific order)
+    const uint8_t *lag_mask; // [nrows] or nullptr = every owned row
+    int row_begin, nrows, nblocks;
+    uint32_t xor80;
+    int32_t *lag;           // [T][nrows] per-block outputs
+    float *mag, *frac;
+    int32_t *lag_state;     // [nrows] last known lag per row (carried across batches)
+    float *mag_state, *frac_state;
+};
+
+// A row that did not request a lag keeps its previous lag/mag/frac (src/ccoherent.cc:266: only
+// is_lagrequested() devices are queued): the workgroup just republishes the state and leaves.
+__device__ __forceinline__ bool xcorr_skip(const XcorrArgs &a, int row, int t, int tid)
+{
+    if (!a.lag_mask || a.lag_mask[row]) return false;
+    if (tid == 0) {
+        const size_t o = (size_t)t * a.nrows + row;
+        a.lag[o] = a.lag_state[row];
+        a.mag[o] = a.mag_state[row];
+        a.frac[o] = a.frac_state[row];
+    }
+    return true;
+}
+
+__device__ __forceinline__ void xcorr_publish(const XcorrArgs &a, int row, int t, int lag, float mag, float frac)
+{
+    const size_t o = (size_t)t * a.nrows + row;
+    a.lag[o] = lag;
+    a.mag[o] = mag;
+    a.frac[o] = frac;
+    if (t == a.nblocks - 1) { // what csdrdevice::set_lag leaves in lagp (include/csdrdevice.h:138-151)
+        a.lag_state[row] = lag;
+        a.mag_state[row] = mag;
+        a.frac_state[row] = frac;
+    }
+}
+
+// K2a / K2b (phase estimate, rotate, quantise): grid = (rows, T blocks)
+struct AlignArgs {
+    const int8_t *rows;       // batch base, block t at rows + t*block_stride
+    size_t block_stride;
+    int8_t *packet;           // block t at packet + t*packet_stride: hdr + readcnt + matrix
+    size_t packet_stride;
+    const uint32_t *readcnt;  // device [T][nrows] or nullptr (use seq + t)
+    const uint8_t *lag_mask;  // [nrows] or nullptr
+    const int32_t *lag;       // [T][nrows] (K1 outputs of this batch)
+    const int32_t *lag_state; // [nrows]
+    long long *corr;          // [T][nrows][2] exact integer correlation sums
+    const float2 *phase_in;   // [nrows] csdrdevice::phasecorr before this batch
+    float2 *phase_out;        // [nrows] ... after it (double-buffered: other blocks still read phase_in)
+    float2 *phasor;           // [T][nrows] get_phasecorrect() after each block
+    int nrows, B, row_begin, nblocks;
+    int digital, refnoise, xcorr_ran;
+    uint32_t seq, xor80;
+};
+
+} // namespace crsdr

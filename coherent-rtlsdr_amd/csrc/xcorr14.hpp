@@ -1,0 +1,351 @@
+// xcorr14.hpp -- the B = 16384 (L = 8192) specialisation of K0 / K1: the configuration every
+// BASELINE.json config except cfg5 runs at.
+//
+// One 512-thread workgroup per row, 32 points per thread in registers, the row resident in LDS
+// (128 KiB + 4 KiB padding of the CU's 160 KiB):
+//
+//   16384 = 32 x 32 x 16      P0 radix-32 (stride 512)  P1 radix-32 (stride 16)  J radix-16 (stride 1)
+//
+//   K1:  int8 HBM --P0--> LDS --P1--> LDS --J: DFT16 . conj(ref) . IDFT16--> LDS --P1'--> LDS --P0'--> |.|^2, argmax
+//
+// i.e. 4 LDS exchanges for the forward + inverse transform pair (a Stockham radix-16 chain needs 7).
+//   * P0 reads the int8 row straight from HBM (2-byte lane loads, 128 B per wave-instruction) and
+//     prunes the zero half of the reference's zero-padding (src/crtlsdr.cc:205-207,215-218):
+//     the first radix-2 stage of the radix-32 butterfly has one zero input.
+//   * DIF forward / DIT inverse: the spectrum is never reordered; the reference spectrum K0 leaves
+//     in HBM is in the same digit-reversed order, laid out [slot][group] so the J pass reads it
+//     with coalesced 16-byte loads.
+//   * inter-pass twiddles: five table values w^1,w^2,w^4,w^8,w^16 per thread and pass (tables are
+//     laid out so the loads coalesce) and 26 complex products; product depth <= 4, so every
+//     twiddle is within ~3 ulp of the correctly rounded value.
+//   * LDS layout: one 16-element (128 B) group pad after every 512 elements plus an XOR swizzle of
+//     the 16-byte slots inside each group, keyed on group-index bits 1..3 -- conflict-free for the
+//     stride-512 (b64), stride-16 (b64) and stride-1 (b128) access patterns of the three passes.
+#pragma once
+#include "arith.hpp"
+#include "fft_lds.hpp"
+#include "plan_args.hpp"
+#include <stdint.h>
+
+namespace crsdr {
+namespace x14 {
+
+constexpr int N = 16384, L = 8192, THREADS = 512;
+constexpr int LDS_ELEMS = (1024 + 32) * 16; // 1024 groups of 16 + one pad group per 32
+constexpr int LDS_BYTES = LDS_ELEMS * 8 + 512;
+constexpr int TWA_STRIDE = 512, TWB_STRIDE = 16; // [5][512] W_16384^(t 2^j), [5][16] W_512^(n 2^j)
+
+// cos / sin (pi k / 16), k = 0..16
+__device__ constexpr float kCos16[17] = {1.0f,
+                                         0.98078528040323044913f,
+                                         0.92387953251128675613f,
+                                         0.83146961230254523708f,
+                                         0.70710678118654752440f,
+                                         0.55557023301960222474f,
+                                         0.38268343236508977173f,
+                                         0.19509032201612826785f,
+                                         0.0f,
+                                         -0.19509032201612826785f,
+                                         -0.38268343236508977173f,
+                                         -0.55557023301960222474f,
+                                         -0.70710678118654752440f,
+                                         -0.83146961230254523708f,
+                                         -0.92387953251128675613f,
+                                         -0.98078528040323044913f,
+                                         -1.0f};
+
+// a * W_32^K  (forward exp(-2 pi i K / 32); DIR > 0: conjugate), K in [0,16)
+template <int DIR, int K>
+__device__ __forceinline__ float2 mul_w32(float2 a)
+{
+    if constexpr (K == 0) return a;
+    else if constexpr (K == 8) return mul_j<DIR>(a);
+    else if constexpr (K == 4) return mul_w16<DIR, 2>(a);
+    else if constexpr (K == 12) return mul_w16<DIR, 6>(a);
+    else {
+        // sin(pi K/16) = cos(pi |8-K| / 16) for K in (0,16)
+        constexpr float c = kCos16[K], sn = kCos16[K < 8 ? 8 - K : K - 8];
+        return DIR < 0 ? make_float2(fmaf(a.x, c, a.y * sn), fmaf(a.y, c, -a.x * sn))
+                       : make_float2(fmaf(a.x, c, -a.y * sn), fmaf(a.y, c, a.x * sn));
+    }
+}
+
+template <int DIR>
+__device__ __forceinline__ void dft16p(float2 *v)
+{
+    dft16<DIR>(*reinterpret_cast<float2(*)[16]>(v));
+}
+
+template <int DIR, int I>
+__device__ __forceinline__ void dft32_stage1(float2 *v)
+{
+    if constexpr (I < 16) {
+        float2 t = csub(v[I], v[I + 16]);
+        v[I] = cadd(v[I], v[I + 16]);
+        v[I + 16] = mul_w32<DIR, I>(t);
+        dft32_stage1<DIR, I + 1>(v);
+    }
+}
+
+// 32-point DFT, natural-order input v[0..32); output X[k] is left in v[(k & 1) * 16 + (k >> 1)]
+template <int DIR>
+__device__ __forceinline__ void dft32(float2 *v)
+{
+    dft32_stage1<DIR, 0>(v);
+    dft16p<DIR>(v);
+    dft16p<DIR>(v + 16);
+}
+__device__ __forceinline__ constexpr int xpos(int k) { return (k & 1) * 16 + (k >> 1); }
+
+// pruned first stage for the zero-padded rows: v[0..16) holds the 16 non-zero inputs.
+// signal rows (zeros in the upper half):  a_i = x_i,      b_i =  x_i W^i
+// ref row     (zeros in the lower half):  a_i = x_{i+16}, b_i = -x_{i+16} W^i
+template <int I, bool IS_REF>
+__device__ __forceinline__ void dft32_stage1_pruned(float2 *v)
+{
+    if constexpr (I < 16) {
+        float2 b = mul_w32<-1, I>(v[I]);
+        v[I + 16] = IS_REF ? make_float2(-b.x, -b.y) : b;
+        dft32_stage1_pruned<I + 1, IS_REF>(v);
+    }
+}
+
+// twiddles w[k] = w1^k, k in [1,32), from the five table values (product depth <= 4)
+template <int K>
+__device__ __forceinline__ void tw_chain(float2 *w)
+{
+    if constexpr (K < 32) {
+        constexpr int hb = (K >= 16) ? 16 : (K >= 8) ? 8 : (K >= 4) ? 4 : (K >= 2) ? 2 : 1;
+        if constexpr (K != hb) w[K] = cmul(w[K - hb], w[hb]);
+        tw_chain<K + 1>(w);
+    }
+}
+__device__ __forceinline__ void tw_load(float2 *w, const float2 *__restrict__ tab, int stride, int idx)
+{
+    w[1] = tab[idx];
+    w[2] = tab[stride + idx];
+    w[4] = tab[2 * stride + idx];
+    w[8] = tab[3 * stride + idx];
+    w[16] = tab[4 * stride + idx];
+    tw_chain<3>(w);
+}
+template <int DIR, bool DIF_LAYOUT, int K>
+__device__ __forceinline__ void tw_apply(float2 *v, const float2 *w)
+{
+    if constexpr (K < 32) {
+        // DIF: the value for output k sits at xpos(k); DIT: input k sits at k
+        constexpr int pos = DIF_LAYOUT ? xpos(K) : K;
+        v[pos] = ctw<DIR>(v[pos], w[K]);
+        tw_apply<DIR, DIF_LAYOUT, K + 1>(v, w);
+    }
+}
+
+// ---- LDS addressing (float2 element index) ------------------------------------------------------
+// P0 / P0': element k*512 + t  ->  k*528 + p0_base(t)
+__device__ __forceinline__ int p0_base(int t) { return ((t >> 4) << 4) + ((t & 15) ^ (((t >> 5) & 7) << 1)); }
+// P1 / P1': element blk*512 + i*16 + n2  ->  blk*528 + i*16 + (n2 ^ (((i>>1)&7)<<1))
+__device__ __forceinline__ constexpr int p1_swz(int i) { return ((i >> 1) & 7) << 1; }
+// J: group g (16 elements): 16-byte slot j lives at float4 index (g + (g>>5))*8 + (j ^ ((g>>1)&7))
+
+template <bool IS_REF>
+__device__ __forceinline__ void pass0_forward(float2 *A, const int8_t *__restrict__ row, const float2 *__restrict__ twA,
+                                              uint32_t xor80, int tid)
+{
+    float2 v[32];
+    const uint16_t *src = reinterpret_cast<const uint16_t *>(row);
+    const uint32_t x16 = xor80 & 0xFFFFu;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const uint32_t u = (uint32_t)src[i * 512 + tid] ^ x16;
+        v[i] = make_float2(i8_to_f32(sext8(u, 0)), i8_to_f32(sext8(u, 1)));
+    }
+    dft32_stage1_pruned<0, IS_REF>(v);
+    dft16p<-1>(v);
+    dft16p<-1>(v + 16);
+    float2 w[32];
+    tw_load(w, twA, TWA_STRIDE, tid);
+    tw_apply<-1, true, 1>(v, w);
+    const int base = p0_base(tid);
+#pragma unroll
+    for (int k = 0; k < 32; ++k) A[base + k * 528] = v[xpos(k)];
+}
+
+__device__ __forceinline__ void pass1_forward(float2 *A, const float2 *__restrict__ twB, int tid)
+{
+    const int blk = tid >> 4, n2 = tid & 15;
+    float2 *Ab = A + blk * 528;
+    float2 v[32];
+#pragma unroll
+    for (int i = 0; i < 32; ++i) v[i] = Ab[i * 16 + (n2 ^ p1_swz(i))];
+    dft32<-1>(v);
+    float2 w[32];
+    tw_load(w, twB, TWB_STRIDE, n2);
+    tw_apply<-1, true, 1>(v, w);
+#pragma unroll
+    for (int k = 0; k < 32; ++k) Ab[k * 16 + (n2 ^ p1_swz(k))] = v[xpos(k)];
+}
+
+__device__ __forceinline__ void pass1_inverse(float2 *A, const float2 *__restrict__ twB, int tid)
+{
+    const int blk = tid >> 4, n2 = tid & 15;
+    float2 *Ab = A + blk * 528;
+    float2 v[32];
+#pragma unroll
+    for (int k = 0; k < 32; ++k) v[k] = Ab[k * 16 + (n2 ^ p1_swz(k))];
+    float2 w[32];
+    tw_load(w, twB, TWB_STRIDE, n2);
+    tw_apply<+1, false, 1>(v, w);
+    dft32<+1>(v);
+#pragma unroll
+    for (int i = 0; i < 32; ++i) Ab[i * 16 + (n2 ^ p1_swz(i))] = v[xpos(i)];
+}
+
+// ---- K0: reference spectrum, conj, [slot][group] layout ------------------------------------------
+__global__ __launch_bounds__(THREADS, 2) void k_ref_spectrum14(const int8_t *__restrict__ rows, size_t block_stride,
+                                                               const float2 *__restrict__ twA,
+                                                               const float2 *__restrict__ twB,
+                                                               float4 *__restrict__ refspec_base, uint32_t xor80)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float2 *A = reinterpret_cast<float2 *>(smem);
+    const float4 *A4 = reinterpret_cast<const float4 *>(smem);
+    const int tid = threadIdx.x;
+    const int8_t *ref_row = rows + (size_t)blockIdx.x * block_stride; // row 0 of batch block blockIdx.x
+    float4 *refspec4 = refspec_base + (size_t)blockIdx.x * (N / 2);
+    pass0_forward<true>(A, ref_row, twA, xor80, tid);
+    __syncthreads();
+    pass1_forward(A, twB, tid);
+    __syncthreads();
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int g = tid + 512 * h, base = (g + (g >> 5)) * 8, key = (g >> 1) & 7;
+        float2 u[16];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float4 q = A4[base + (j ^ key)];
+            u[2 * j] = make_float2(q.x, q.y);
+            u[2 * j + 1] = make_float2(q.z, q.w);
+        }
+        dft16p<-1>(u);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) // conj(sfft[0]) for the conjugate multiply of src/ccoherent.cc:177-179
+            refspec4[j * 1024 + g] = make_float4(u[2 * j].x, -u[2 * j].y, u[2 * j + 1].x, -u[2 * j + 1].y);
+    }
+}
+
+// ---- K1 -------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(THREADS, 2) void k_xcorr_lag14(XcorrArgs a, const float2 *__restrict__ twA,
+                                                            const float2 *__restrict__ twB)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float2 *A = reinterpret_cast<float2 *>(smem);
+    float4 *A4 = reinterpret_cast<float4 *>(smem);
+    float *red = reinterpret_cast<float *>(smem + (size_t)LDS_ELEMS * 8); // 128 floats of scratch
+    const int tid = threadIdx.x;
+    const int row = a.row_begin + blockIdx.x, t = blockIdx.y;
+    if (xcorr_skip(a, row, t, tid)) return;
+    const float4 *__restrict__ refspec4 = reinterpret_cast<const float4 *>(a.refspec) + (size_t)t * (N / 2);
+
+    pass0_forward<false>(A, a.rows + (size_t)t * a.block_stride + (size_t)row * N, twA, a.xor80, tid);
+    __syncthreads();
+    pass1_forward(A, twB, tid);
+    __syncthreads();
+    // junction: DFT16 . conj(ref spectrum) . IDFT16 on the same 16 contiguous points
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int g = tid + 512 * h, base = (g + (g >> 5)) * 8, key = (g >> 1) & 7;
+        float4 r[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) r[j] = refspec4[j * 1024 + g];
+        float2 u[16];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float4 q = A4[base + (j ^ key)];
+            u[2 * j] = make_float2(q.x, q.y);
+            u[2 * j + 1] = make_float2(q.z, q.w);
+        }
+        dft16p<-1>(u);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            u[2 * j] = cmul(u[2 * j], make_float2(r[j].x, r[j].y));
+            u[2 * j + 1] = cmul(u[2 * j + 1], make_float2(r[j].z, r[j].w));
+        }
+        dft16p<+1>(u);
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            A4[base + (j ^ key)] = make_float4(u[2 * j].x, u[2 * j].y, u[2 * j + 1].x, u[2 * j + 1].y);
+    }
+    __syncthreads();
+    pass1_inverse(A, twB, tid);
+    __syncthreads();
+    // final inverse pass fused with |.|^2 (cdsp::magsquared) and the argmax (cdsp::indexofmax)
+    float m[32];
+    float bm;
+    int bi;
+    {
+        float2 v[32];
+        const int base = p0_base(tid);
+#pragma unroll
+        for (int k = 0; k < 32; ++k) v[k] = A[base + k * 528];
+        float2 w[32];
+        tw_load(w, twA, TWA_STRIDE, tid);
+        tw_apply<+1, false, 1>(v, w);
+        dft32<+1>(v);
+#pragma unroll
+        for (int i = 0; i < 32; ++i) {
+            const float2 x = v[xpos(i)];
+            m[i] = fmaf(x.x, x.x, x.y * x.y);
+        }
+        // natural index of output i is i*512 + tid: ascending in i, strict > keeps the first maximum
+        bm = m[0];
+        bi = tid;
+#pragma unroll
+        for (int i = 1; i < 32; ++i)
+            if (m[i] > bm) { bm = m[i]; bi = i * 512 + tid; }
+    }
+    // wavefront argmax over 64 lanes (ties -> lowest index), then across the 8 waves through LDS
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        const float om = __shfl_xor(bm, off, 64);
+        const int oi = __shfl_xor(bi, off, 64);
+        if (om > bm || (om == bm && oi < bi)) { bm = om; bi = oi; }
+    }
+    int *redi = reinterpret_cast<int *>(red);
+    if ((tid & 63) == 0) { red[2 * (tid >> 6)] = bm; redi[2 * (tid >> 6) + 1] = bi; }
+    __syncthreads();
+    float gm = red[0];
+    int gi = redi[1];
+#pragma unroll
+    for (int wv = 1; wv < THREADS / 64; ++wv) {
+        const float om = red[2 * wv];
+        const int oi = redi[2 * wv + 1];
+        if (om > gm || (om == gm && oi < gi)) { gm = om; gi = oi; }
+    }
+    if ((unsigned)gi >= (unsigned)N) gi = 0; // all-NaN row: defined as index 0
+    // neighbours of the peak for the parabolic estimate: their owners publish them
+    {
+        const int nl = gi - 1, nr = gi + 1;
+        float ml = 0.f, mr = 0.f;
+        const int il = nl >> 9, ir = nr >> 9;
+#pragma unroll
+        for (int i = 0; i < 32; ++i) {
+            ml = (i == il) ? m[i] : ml;
+            mr = (i == ir) ? m[i] : mr;
+        }
+        if (gi > 0 && (nl & 511) == tid) red[32] = ml;
+        if (gi < N - 1 && (nr & 511) == tid) red[33] = mr;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        float D = 0.0f;
+        if (gi > 0 && gi < N - 1) {
+            const float ym = red[32], yp = red[33];
+            const float den = (ym - 2.0f * gm) + yp;
+            if (den != 0.0f) D = (0.5f * (ym - yp)) / den;
+        }
+        xcorr_publish(a, row, t, gi - L /* src/ccoherent.cc:232 */, sqrtf(gm / (float)L) /* :204 */, D);
+    }
+}
+
+} // namespace x14
+} // namespace crsdr

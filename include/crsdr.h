@@ -126,7 +126,9 @@ typedef struct crsdr_plan_desc {
     int32_t row_begin;  /* first signal row this plan owns (>= 1); 0 = default (1) */
     int32_t row_count;  /* signal rows owned; 0 = default (all: nrows - row_begin).  Multi-GPU:
                            rank g owns a contiguous slab, the ref row is replicated */
-    uint32_t reserved[2];
+    int32_t max_batch;  /* most consecutive blocks one crsdr_plan_submit_batch may carry (1..64);
+                           0 = default (1).  Sizes every per-block device buffer. */
+    uint32_t reserved;
 } crsdr_plan_desc;
 
 /* ccoherent::ccoherent (src/ccoherent.cc:32-95): allocates every device buffer, twiddle table,
@@ -155,6 +157,18 @@ int crsdr_plan_set_stream(crsdr_plan *plan, void *hip_stream);
 int crsdr_plan_submit(crsdr_plan *plan, const void *rows, int mem_kind, const uint32_t *readcnt,
                       const uint8_t *lag_mask, uint32_t seq, uint32_t flags);
 
+/* nblocks consecutive ccoherent::threadf iterations in one submit: the same results as nblocks
+ * crsdr_plan_submit calls in a row (the EMA phasor and the last lag are carried from block to
+ * block), but every kernel is launched once over nblocks x rows workgroups -- host cost and
+ * launch gaps are paid per batch, and a GPU that owns a small slab still fills its 256 CUs.
+ *   rows          block t at rows + t * block_stride (bytes; 0 = nrows * B, i.e. contiguous)
+ *   readcnt       [nblocks][nrows] or NULL (block t gets seq + t)
+ *   lag_mask      [nrows], applies to every block of the batch
+ *   seq           hdr0::globalseqn of block 0; block t gets seq + t
+ * Packets land at device_packet + t * packet_stride. */
+int crsdr_plan_submit_batch(crsdr_plan *plan, const void *rows, int mem_kind, int nblocks, size_t block_stride,
+                            const uint32_t *readcnt, const uint8_t *lag_mask, uint32_t seq, uint32_t flags);
+
 /* Wait for the last submitted block and copy results to host arrays (any may be NULL):
  *   lag    [nrows] int32  idx - L, what csdrdevice::set_lag receives (src/ccoherent.cc:232)
  *   mag    [nrows] float  sqrt(peak / L)                         (src/ccoherent.cc:204)
@@ -167,30 +181,37 @@ int crsdr_plan_submit(crsdr_plan *plan, const void *rows, int mem_kind, const ui
  * Rows outside the plan's slab hold whatever the bound buffer held (zeros by default). */
 int crsdr_plan_fetch(crsdr_plan *plan, int32_t *lag, float *mag, float *frac, float *phasor,
                      int8_t *packet);
+/* Same for block `block` (0-based) of the last submitted batch; -1 = its last block, which is
+ * what crsdr_plan_fetch returns. */
+int crsdr_plan_fetch_block(crsdr_plan *plan, int block, int32_t *lag, float *mag, float *frac, float *phasor,
+                           int8_t *packet);
 
 /* Block until everything submitted so far has finished (no copies). */
 int crsdr_plan_sync(crsdr_plan *plan);
 
 size_t crsdr_plan_packet_bytes(const crsdr_plan *plan);   /* 16 + 4N + N*B */
 size_t crsdr_plan_matrix_offset(const crsdr_plan *plan);  /* 16 + 4N */
+size_t crsdr_plan_packet_stride(const crsdr_plan *plan);  /* bytes between the packets of a batch */
 
 /* Device-resident results for pipelines that never leave HBM (multi-GPU gather, benchmarks).
- * The packet pointer is 4-byte aligned and the matrix inside it 256-byte aligned. */
+ * The packet pointer is 4-byte aligned and the matrix inside it 256-byte aligned; per-row arrays
+ * are [max_batch][nrows] (block t of the last batch at + t * nrows). */
 int crsdr_plan_device_buffers(crsdr_plan *plan, void **packet, void **lag, void **mag,
                               void **frac, void **phasor);
-/* Write the packets of later submits into a caller-owned device buffer instead (>= packet_bytes,
- * matrix start 4-byte aligned); NULL restores the plan's own buffer.  Does not synchronise:
- * double-buffering against a gather in flight is the caller's business. */
-int crsdr_plan_bind_packet(crsdr_plan *plan, void *device_packet);
+/* Write the packets of later submits into a caller-owned device buffer instead: block t of a
+ * batch at device_packet + t * packet_stride (matrix start and stride 4-byte aligned, stride >=
+ * packet_bytes); NULL restores the plan's own buffer.  Does not synchronise: double-buffering
+ * against a gather in flight is the caller's business. */
+int crsdr_plan_bind_packet(crsdr_plan *plan, void *device_packet, size_t packet_stride);
 
-/* Elapsed GPU milliseconds between the start of the first and the end of the last kernel of
- * the most recent submit (hipEvents on the plan's stream). */
+/* With profiling enabled: elapsed GPU milliseconds on the plan's stream between the start and
+ * the end of the most recent submit. */
 int crsdr_plan_last_elapsed_ms(crsdr_plan *plan, float *ms);
 
 /* Per-kernel timing with hipEvents recorded on the stream each kernel is launched on.
  * enable: keep event pairs for the last `slots` submits (0 disables).  kernel_times: copy the
  * durations (ms) of kernel `which` for the submits recorded since enable, oldest first. */
-enum { CRSDR_KERNEL_REF_SPECTRUM = 0, CRSDR_KERNEL_XCORR_LAG = 1, CRSDR_KERNEL_ALIGN_QUANT = 2 };
+enum { CRSDR_KERNEL_REF_SPECTRUM = 0, CRSDR_KERNEL_XCORR_LAG = 1, CRSDR_KERNEL_PHASE_DOT = 2, CRSDR_KERNEL_ALIGN_QUANT = 3 };
 int crsdr_plan_enable_profiling(crsdr_plan *plan, int slots);
 int crsdr_plan_kernel_times(crsdr_plan *plan, int which, float *ms, int capacity, int *count);
 

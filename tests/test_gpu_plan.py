@@ -211,3 +211,39 @@ def test_async_pipeline_equals_blockwise(b, synth):
     piped = p2.fetch()
     for k in ("lag", "mag", "phasor", "packet"):
         assert np.array_equal(last[k], piped[k]), k
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+def test_batched_submit_equals_blockwise(b, oracle, synth, mode):
+    # crsdr_plan_submit_batch: T blocks in one submit == T submits in a row, bit for bit, for
+    # every block of the batch (EMA phasor and last lag are carried block to block), including a
+    # lag mask (rows that are not requested keep the lag of an earlier batch) and a second batch.
+    nsig, L, T = 6, 2048, 4
+    params = synth.RowParams(nsig, L, 31, dmax=300)
+    blocks = np.stack([synth.make_block(nsig, L, 31, t, params=params)[0] for t in range(2 * T)])
+    one, many = b.Plan(nsig + 1, 2 * L, mode), b.Plan(nsig + 1, 2 * L, mode, max_batch=T)
+    orc = oracle.Engine(nsig + 1, 2 * L, mode)
+    mask = np.ones(nsig + 1, dtype=np.uint8)
+    ref_out = []
+    for t in range(2 * T):
+        mk = mask if t < T else np.array([0, 1, 0, 1, 0, 1, 0], dtype=np.uint8)
+        ref_out.append(one.block(blocks[t], seq=100 + t, lag_mask=mk))
+        _compare(ref_out[-1], orc.block(blocks[t], seq=100 + t, lag_mask=mk), phase_tol=1e-5 if mode == 1 else 2e-4)
+    for half in range(2):
+        mk = mask if half == 0 else np.array([0, 1, 0, 1, 0, 1, 0], dtype=np.uint8)
+        many.submit(blocks[half * T:(half + 1) * T], seq=100 + half * T, lag_mask=mk)
+        for t in range(T):
+            got = many.fetch(block=t)
+            exp = ref_out[half * T + t]
+            for k in ("lag", "mag", "frac", "phasor", "packet"):
+                assert np.array_equal(got[k], exp[k]), (half, t, k)
+    one.close(); many.close()
+
+
+def test_batch_argument_checks(b):
+    plan = b.Plan(3, 1024, max_batch=2)
+    with pytest.raises(b.CrsdrError):
+        plan.submit(np.zeros((3, 3, 1024), dtype=np.int8))      # more blocks than max_batch
+    with pytest.raises(b.CrsdrError):
+        b.Plan(3, 1024, max_batch=1000)
+    plan.close()
