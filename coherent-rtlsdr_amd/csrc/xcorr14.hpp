@@ -18,14 +18,25 @@
 //   * inter-pass twiddles: five table values w^1,w^2,w^4,w^8,w^16 per thread and pass (tables are
 //     laid out so the loads coalesce) and 26 complex products; product depth <= 4, so every
 //     twiddle is within ~3 ulp of the correctly rounded value.
-//   * LDS layout: one 16-element (128 B) group pad after every 512 elements plus an XOR swizzle of
-//     the 16-byte slots inside each group, keyed on group-index bits 1..3 -- conflict-free for the
-//     stride-512 (b64), stride-16 (b64) and stride-1 (b128) access patterns of the three passes.
+//   * LDS layout: one 16-element (128 B) group pad after every 512 elements plus an XOR swizzle
+//     keyed on the group index G = e >> 4: 16-byte slot s of group G lives at slot s ^ (G & 7) of
+//     group G ^ ((G >> 3) & 1) -- conflict-free for the stride-512 (b64), stride-16 (b64) and
+//     stride-1 (b128 reads in 16-lane groups, b128 writes in 8-lane groups) access patterns.
+//   * only P0 -> P1 and P1' -> P0' are workgroup-wide exchanges (2 barriers per row): P1, J and
+//     P1' of a 512-element sub-block are produced and consumed by the same wave (a wave's 64
+//     threads own 4 sub-blocks = 128 J groups), so that section needs only wave-level ordering
+//     and the 8 waves drift apart, overlapping one wave's LDS traffic with another's VALU work.
 #pragma once
 #include "arith.hpp"
 #include "fft_lds.hpp"
 #include "plan_args.hpp"
 #include <stdint.h>
+
+// Diagnostic builds (tools/k1_phases.hip) define CRSDR_STAMP(i) to record s_memtime at phase
+// boundaries; in the product build it expands to nothing and no stamp executes.
+#ifndef CRSDR_STAMP
+#define CRSDR_STAMP(i)
+#endif
 
 namespace crsdr {
 namespace x14 {
@@ -34,6 +45,9 @@ constexpr int N = 16384, L = 8192, THREADS = 512;
 constexpr int LDS_ELEMS = (1024 + 32) * 16; // 1024 groups of 16 + one pad group per 32
 constexpr int LDS_BYTES = LDS_ELEMS * 8 + 512;
 constexpr int TWA_STRIDE = 512, TWB_STRIDE = 16; // [5][512] W_16384^(t 2^j), [5][16] W_512^(n 2^j)
+// |ifft|^2 of unscaled int8 data is (127^2)^2 times the reference's value (signal and ref spectra
+// each carry one factor 127): mag = sqrt(peak / L) / 127^2
+constexpr float kInvScale2 = 1.0f / (127.0f * 127.0f);
 
 // cos / sin (pi k / 16), k = 0..16
 __device__ constexpr float kCos16[17] = {1.0f,
@@ -141,11 +155,30 @@ __device__ __forceinline__ void tw_apply(float2 *v, const float2 *w)
 }
 
 // ---- LDS addressing (float2 element index) ------------------------------------------------------
-// P0 / P0': element k*512 + t  ->  k*528 + p0_base(t)
-__device__ __forceinline__ int p0_base(int t) { return ((t >> 4) << 4) + ((t & 15) ^ (((t >> 5) & 7) << 1)); }
-// P1 / P1': element blk*512 + i*16 + n2  ->  blk*528 + i*16 + (n2 ^ (((i>>1)&7)<<1))
-__device__ __forceinline__ constexpr int p1_swz(int i) { return ((i >> 1) & 7) << 1; }
-// J: group g (16 elements): 16-byte slot j lives at float4 index (g + (g>>5))*8 + (j ^ ((g>>1)&7))
+// generic: element e -> G = e>>4, s = e&15; group' = G ^ ((G>>3)&1); slot' = (s>>1) ^ (G&7);
+//          phys = (group' + (group'>>5))*16 + 2*slot' + (s&1)
+// P0 / P0': element k*512 + t  ->  k*528 + p0_base(t)      (G = 32k + (t>>4): G&7 = (t>>4)&7, (G>>3)&1 = (t>>7)&1)
+__device__ __forceinline__ int p0_base(int t)
+{
+    return ((((t >> 4) ^ ((t >> 7) & 1))) << 4) + ((t & 15) ^ (((t >> 4) & 7) << 1));
+}
+// P1 / P1': element blk*512 + i*16 + n2  ->  blk*528 + p1_off(i) + (n2 ^ p1_swz(i))   (G = 32 blk + i)
+__device__ __forceinline__ constexpr int p1_off(int i) { return (i ^ ((i >> 3) & 1)) << 4; }
+__device__ __forceinline__ constexpr int p1_swz(int i) { return (i & 7) << 1; }
+// J: group g (16 elements): 16-byte slot j lives at float4 index j_base(g) + (j ^ (g & 7))
+__device__ __forceinline__ int j_base(int g)
+{
+    const int gp = g ^ ((g >> 3) & 1);
+    return (gp + (gp >> 5)) * 8;
+}
+// wave-level ordering of LDS traffic inside the wave-local section: LDS operations of one wave
+// execute in issue order, so waiting for this wave's own outstanding LDS ops is sufficient.
+__device__ __forceinline__ void wave_lds_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
 
 template <bool IS_REF>
 __device__ __forceinline__ void pass0_forward(float2 *A, const int8_t *__restrict__ row, const float2 *__restrict__ twA,
@@ -156,8 +189,10 @@ __device__ __forceinline__ void pass0_forward(float2 *A, const int8_t *__restric
     const uint32_t x16 = xor80 & 0xFFFFu;
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
+        // integer-valued floats: the 1/127 of cdsp::convtofloat (src/cdsp.cc:41-44) is a common
+        // factor of the whole linear chain and is applied once, to the peak (kInvScale4 below)
         const uint32_t u = (uint32_t)src[i * 512 + tid] ^ x16;
-        v[i] = make_float2(i8_to_f32(sext8(u, 0)), i8_to_f32(sext8(u, 1)));
+        v[i] = make_float2((float)sext8(u, 0), (float)sext8(u, 1));
     }
     dft32_stage1_pruned<0, IS_REF>(v);
     dft16p<-1>(v);
@@ -170,34 +205,30 @@ __device__ __forceinline__ void pass0_forward(float2 *A, const int8_t *__restric
     for (int k = 0; k < 32; ++k) A[base + k * 528] = v[xpos(k)];
 }
 
-__device__ __forceinline__ void pass1_forward(float2 *A, const float2 *__restrict__ twB, int tid)
+__device__ __forceinline__ void pass1_forward(float2 *A, const float2 *w, int tid)
 {
     const int blk = tid >> 4, n2 = tid & 15;
     float2 *Ab = A + blk * 528;
     float2 v[32];
 #pragma unroll
-    for (int i = 0; i < 32; ++i) v[i] = Ab[i * 16 + (n2 ^ p1_swz(i))];
+    for (int i = 0; i < 32; ++i) v[i] = Ab[p1_off(i) + (n2 ^ p1_swz(i))];
     dft32<-1>(v);
-    float2 w[32];
-    tw_load(w, twB, TWB_STRIDE, n2);
     tw_apply<-1, true, 1>(v, w);
 #pragma unroll
-    for (int k = 0; k < 32; ++k) Ab[k * 16 + (n2 ^ p1_swz(k))] = v[xpos(k)];
+    for (int k = 0; k < 32; ++k) Ab[p1_off(k) + (n2 ^ p1_swz(k))] = v[xpos(k)];
 }
 
-__device__ __forceinline__ void pass1_inverse(float2 *A, const float2 *__restrict__ twB, int tid)
+__device__ __forceinline__ void pass1_inverse(float2 *A, const float2 *w, int tid)
 {
     const int blk = tid >> 4, n2 = tid & 15;
     float2 *Ab = A + blk * 528;
     float2 v[32];
 #pragma unroll
-    for (int k = 0; k < 32; ++k) v[k] = Ab[k * 16 + (n2 ^ p1_swz(k))];
-    float2 w[32];
-    tw_load(w, twB, TWB_STRIDE, n2);
+    for (int k = 0; k < 32; ++k) v[k] = Ab[p1_off(k) + (n2 ^ p1_swz(k))];
     tw_apply<+1, false, 1>(v, w);
     dft32<+1>(v);
 #pragma unroll
-    for (int i = 0; i < 32; ++i) Ab[i * 16 + (n2 ^ p1_swz(i))] = v[xpos(i)];
+    for (int i = 0; i < 32; ++i) Ab[p1_off(i) + (n2 ^ p1_swz(i))] = v[xpos(i)];
 }
 
 // ---- K0: reference spectrum, conj, [slot][group] layout ------------------------------------------
@@ -213,12 +244,15 @@ __global__ __launch_bounds__(THREADS, 2) void k_ref_spectrum14(const int8_t *__r
     const int8_t *ref_row = rows + (size_t)blockIdx.x * block_stride; // row 0 of batch block blockIdx.x
     float4 *refspec4 = refspec_base + (size_t)blockIdx.x * (N / 2);
     pass0_forward<true>(A, ref_row, twA, xor80, tid);
+    float2 wB[32];
+    tw_load(wB, twB, TWB_STRIDE, tid & 15);
     __syncthreads();
-    pass1_forward(A, twB, tid);
-    __syncthreads();
+    pass1_forward(A, wB, tid);
+    wave_lds_sync();
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
-        const int g = tid + 512 * h, base = (g + (g >> 5)) * 8, key = (g >> 1) & 7;
+        // the 128 J groups of the 4 sub-blocks this wave produced in P1
+        const int g = ((tid >> 6) << 7) + 64 * h + (tid & 63), base = j_base(g), key = g & 7;
         float2 u[16];
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
@@ -246,14 +280,22 @@ __global__ __launch_bounds__(THREADS, 2) void k_xcorr_lag14(XcorrArgs a, const f
     if (xcorr_skip(a, row, t, tid)) return;
     const float4 *__restrict__ refspec4 = reinterpret_cast<const float4 *>(a.refspec) + (size_t)t * (N / 2);
 
+    CRSDR_STAMP(0);
     pass0_forward<false>(A, a.rows + (size_t)t * a.block_stride + (size_t)row * N, twA, a.xor80, tid);
+    CRSDR_STAMP(1);
+    // P1 / P1' twiddles: one chain per row, computed while the P0 stores drain, alive across J
+    float2 wB[32];
+    tw_load(wB, twB, TWB_STRIDE, tid & 15);
     __syncthreads();
-    pass1_forward(A, twB, tid);
-    __syncthreads();
+    CRSDR_STAMP(2);
+    pass1_forward(A, wB, tid);
+    wave_lds_sync();
+    CRSDR_STAMP(3);
     // junction: DFT16 . conj(ref spectrum) . IDFT16 on the same 16 contiguous points
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
-        const int g = tid + 512 * h, base = (g + (g >> 5)) * 8, key = (g >> 1) & 7;
+        // the 128 J groups of the 4 sub-blocks this wave produced in P1 (and consumes in P1')
+        const int g = ((tid >> 6) << 7) + 64 * h + (tid & 63), base = j_base(g), key = g & 7;
         float4 r[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) r[j] = refspec4[j * 1024 + g];
@@ -275,13 +317,14 @@ __global__ __launch_bounds__(THREADS, 2) void k_xcorr_lag14(XcorrArgs a, const f
         for (int j = 0; j < 8; ++j)
             A4[base + (j ^ key)] = make_float4(u[2 * j].x, u[2 * j].y, u[2 * j + 1].x, u[2 * j + 1].y);
     }
+    wave_lds_sync();
+    CRSDR_STAMP(4);
+    pass1_inverse(A, wB, tid);
+    CRSDR_STAMP(5);
     __syncthreads();
-    pass1_inverse(A, twB, tid);
-    __syncthreads();
+    CRSDR_STAMP(6);
     // final inverse pass fused with |.|^2 (cdsp::magsquared) and the argmax (cdsp::indexofmax)
     float m[32];
-    float bm;
-    int bi;
     {
         float2 v[32];
         const int base = p0_base(tid);
@@ -296,44 +339,49 @@ __global__ __launch_bounds__(THREADS, 2) void k_xcorr_lag14(XcorrArgs a, const f
             const float2 x = v[xpos(i)];
             m[i] = fmaf(x.x, x.x, x.y * x.y);
         }
-        // natural index of output i is i*512 + tid: ascending in i, strict > keeps the first maximum
-        bm = m[0];
-        bi = tid;
-#pragma unroll
-        for (int i = 1; i < 32; ++i)
-            if (m[i] > bm) { bm = m[i]; bi = i * 512 + tid; }
     }
-    // wavefront argmax over 64 lanes (ties -> lowest index), then across the 8 waves through LDS
+    // maximum VALUE first: 16 x v_max3 per thread, a 64-lane butterfly, 8 waves through LDS ...
+    float tm = m[0];
 #pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) {
-        const float om = __shfl_xor(bm, off, 64);
-        const int oi = __shfl_xor(bi, off, 64);
-        if (om > bm || (om == bm && oi < bi)) { bm = om; bi = oi; }
-    }
+    for (int i = 1; i < 31; i += 2) tm = fmaxf(tm, fmaxf(m[i], m[i + 1]));
+    tm = fmaxf(tm, m[31]);
+    CRSDR_STAMP(7);
+    float wm = tm;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) wm = fmaxf(wm, __shfl_xor(wm, off, 64));
     int *redi = reinterpret_cast<int *>(red);
-    if ((tid & 63) == 0) { red[2 * (tid >> 6)] = bm; redi[2 * (tid >> 6) + 1] = bi; }
+    if (tid == 0) redi[16] = 0x7fffffff;
+    if ((tid & 63) == 0) red[tid >> 6] = wm;
     __syncthreads();
     float gm = red[0];
-    int gi = redi[1];
 #pragma unroll
-    for (int wv = 1; wv < THREADS / 64; ++wv) {
-        const float om = red[2 * wv];
-        const int oi = redi[2 * wv + 1];
-        if (om > gm || (om == gm && oi < gi)) { gm = om; gi = oi; }
+    for (int wv = 1; wv < THREADS / 64; ++wv) gm = fmaxf(gm, red[wv]);
+    // ... then its FIRST index (volk_32f_index_max_32u keeps the first strict maximum): only the
+    // threads that hold the maximum search their 32 values (natural index of output i: i*512 + tid)
+    if (tm == gm) {
+        int bi = 0x7fffffff;
+#pragma unroll
+        for (int i = 31; i >= 0; --i) bi = (m[i] == gm) ? i * 512 + tid : bi;
+        atomicMin(&redi[16], bi);
     }
+    __syncthreads();
+    int gi = redi[16];
     if ((unsigned)gi >= (unsigned)N) gi = 0; // all-NaN row: defined as index 0
     // neighbours of the peak for the parabolic estimate: their owners publish them
     {
         const int nl = gi - 1, nr = gi + 1;
-        float ml = 0.f, mr = 0.f;
-        const int il = nl >> 9, ir = nr >> 9;
+        if (gi > 0 && (nl & 511) == tid) {
+            float ml = 0.f;
 #pragma unroll
-        for (int i = 0; i < 32; ++i) {
-            ml = (i == il) ? m[i] : ml;
-            mr = (i == ir) ? m[i] : mr;
+            for (int i = 0; i < 32; ++i) ml = (i == (nl >> 9)) ? m[i] : ml;
+            red[32] = ml;
         }
-        if (gi > 0 && (nl & 511) == tid) red[32] = ml;
-        if (gi < N - 1 && (nr & 511) == tid) red[33] = mr;
+        if (gi < N - 1 && (nr & 511) == tid) {
+            float mr = 0.f;
+#pragma unroll
+            for (int i = 0; i < 32; ++i) mr = (i == (nr >> 9)) ? m[i] : mr;
+            red[33] = mr;
+        }
     }
     __syncthreads();
     if (tid == 0) {
@@ -343,8 +391,9 @@ __global__ __launch_bounds__(THREADS, 2) void k_xcorr_lag14(XcorrArgs a, const f
             const float den = (ym - 2.0f * gm) + yp;
             if (den != 0.0f) D = (0.5f * (ym - yp)) / den;
         }
-        xcorr_publish(a, row, t, gi - L /* src/ccoherent.cc:232 */, sqrtf(gm / (float)L) /* :204 */, D);
+        xcorr_publish(a, row, t, gi - L /* src/ccoherent.cc:232 */, sqrtf(gm / (float)L) * kInvScale2 /* :204 */, D);
     }
+    CRSDR_STAMP(8);
 }
 
 } // namespace x14
