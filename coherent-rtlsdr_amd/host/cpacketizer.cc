@@ -1,0 +1,106 @@
+// cpacketizer.cc -- see cpacketizer.h.  Layout and hand-off follow src/cpacketizer.cc:91-185.
+#include "cpacketizer.h"
+#include "cdsp.h"
+#include <cstring>
+
+int cpacketize::objcount = 0;
+uint32_t cpacketize::globalseqn = 0;
+std::condition_variable cpacketize::cv;
+std::mutex cpacketize::bmutex;
+std::unique_ptr<int8_t[]> cpacketize::packetbuf0;
+std::unique_ptr<int8_t[]> cpacketize::packetbuf1;
+bool cpacketize::noheader = false;
+size_t cpacketize::packetlen = 0;
+bool cpacketize::bufferfilled = false;
+uint32_t cpacketize::blocksize = 0;
+bool cpacketize::do_exit = false;
+std::vector<std::complex<float>> cpacketize::pcorrection;
+cpacketize::sink_t cpacketize::sink;
+
+cpacketize::cpacketize() { objcount++; }                     // src/cpacketizer.cc:45-51
+cpacketize::~cpacketize() { objcount--; }
+
+size_t cpacketize::packetlength(uint32_t N, uint32_t L)
+{
+    return noheader ? (size_t)N * L : (16 + 4 * (size_t)N) + (size_t)N * L;
+}
+
+void cpacketize::resize_buffers(uint32_t N, uint32_t L)
+{
+    std::lock_guard<std::mutex> lock(bmutex);
+    packetlen = packetlength(N, L);
+    packetbuf0.reset(new int8_t[packetlen]());
+    packetbuf1.reset(new int8_t[packetlen]());
+    pcorrection.assign(N, std::complex<float>(0.0f, 0.0f));
+}
+
+void cpacketize::init(std::string /*address*/, bool noheader_, uint32_t nchannels_, uint32_t blocksize_)
+{
+    noheader = noheader_;                                      // src/cpacketizer.cc:58-74
+    blocksize = blocksize_;
+    do_exit = false;
+    bufferfilled = false;
+    globalseqn = 0;
+    resize_buffers(nchannels_, blocksize_);
+}
+
+void cpacketize::cleanup() { packetbuf0.reset(); packetbuf1.reset(); packetlen = 0; }
+void cpacketize::request_exit() { { std::lock_guard<std::mutex> l(bmutex); do_exit = true; } cv.notify_all(); }
+
+int cpacketize::send()
+{
+    {   // src/cpacketizer.cc:119-123: wait for notifysend()
+        std::unique_lock<std::mutex> lock(bmutex);
+        cv.wait(lock, [] { return bufferfilled || do_exit; });
+        if (!bufferfilled) return -1;
+        bufferfilled = false;
+    }
+    if (!noheader) {
+        // header of the buffer that was just swapped out.  (The reference fills packetbuf0's header
+        // before the wait and then sends packetbuf1, src/cpacketizer.cc:110-125, so its sequence
+        // number lags one packet behind the data; here the header belongs to the data it ships with.)
+        hdr0 *hdr = reinterpret_cast<hdr0 *>(packetbuf1.get());
+        hdr->globalseqn = globalseqn++;
+        hdr->N = (uint32_t)objcount;
+        hdr->L = blocksize >> 1;
+        hdr->unused = 0;
+    }
+    if (sink) sink(packetbuf1.get(), packetlen, pcorrection.data(), (size_t)objcount);
+    return 0;
+}
+
+int cpacketize::writedebug(uint32_t channeln, std::complex<float> p)
+{
+    pcorrection[channeln] = p;                                 // src/cpacketizer.cc:131-134
+    return 0;
+}
+
+static inline uint32_t row_offset(bool noheader, int objcount, uint32_t channeln, uint32_t blocksize)
+{
+    return noheader ? channeln * blocksize : (uint32_t)(sizeof(hdr0) + objcount * sizeof(uint32_t)) + channeln * blocksize;
+}
+
+int cpacketize::write(uint32_t channeln, uint32_t readcnt, int8_t *rp)
+{
+    if (!noheader) *(reinterpret_cast<uint32_t *>(packetbuf0.get()) + sizeof(hdr0) / sizeof(uint32_t) + channeln) = readcnt;
+    std::memcpy(packetbuf0.get() + row_offset(noheader, objcount, channeln, blocksize), rp, blocksize); // src/cpacketizer.cc:137-156
+    return 0;
+}
+
+int cpacketize::write(uint32_t channeln, uint32_t readcnt, std::complex<float> *in)
+{
+    if (!noheader) *(reinterpret_cast<uint32_t *>(packetbuf0.get()) + sizeof(hdr0) / sizeof(uint32_t) + channeln) = readcnt;
+    cdsp::convto8bit(reinterpret_cast<std::complex<int8_t> *>(packetbuf0.get() + row_offset(noheader, objcount, channeln, blocksize)),
+                     in, (blocksize >> 1));                    // src/cpacketizer.cc:158-172
+    return 0;
+}
+
+int cpacketize::notifysend()
+{
+    std::unique_lock<std::mutex> lock(bmutex);                 // src/cpacketizer.cc:174-185
+    packetbuf0.swap(packetbuf1);
+    bufferfilled = true;
+    lock.unlock();
+    cv.notify_one();
+    return 0;
+}

@@ -1,0 +1,54 @@
+// cpacketizer.h -- the write side of the reference's cpacketize (include/cpacketizer.h:32-79,
+// src/cpacketizer.cc:91-185): static double-buffered packet  hdr0 + u32 readcnt[N] + int8 IQ[N][L][2].
+// The ZMQ PUB sockets of init()/send() (ports 5555 / 5557) are outside the hot path:
+// send() hands the finished packet and the N phase factors to a sink callback instead.
+#ifndef PACKETIZEH
+#define PACKETIZEH
+#include <complex>
+#include <condition_variable>
+#include <cstdint>
+#include <functional>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <vector>
+
+struct hdr0 { // include/cpacketizer.h:32-37
+    uint32_t globalseqn;
+    uint32_t N;
+    uint32_t L;
+    uint32_t unused;
+};
+
+class cpacketize {
+    static int objcount;
+    static std::mutex bmutex;
+    static std::condition_variable cv;
+    static bool noheader;
+    static size_t packetlen;
+    static uint32_t globalseqn;
+    static bool bufferfilled;
+    static bool do_exit;
+    static uint32_t blocksize;
+    static std::unique_ptr<int8_t[]> packetbuf0, packetbuf1; // one being sent, one written to
+    static std::vector<std::complex<float>> pcorrection;
+    static void resize_buffers(uint32_t N, uint32_t L);
+public:
+    typedef std::function<void(const int8_t *packet, size_t bytes, const std::complex<float> *phase, size_t n)> sink_t;
+    static sink_t sink;
+    // packet bytes for N channels of blocksize L: (16 + 4N) + N*L.  The reference allocates and
+    // sends 2*N*L data bytes (src/cpacketizer.cc:95), of which clients read N*L
+    // (matlabclient/zmqsdr.c:121-143); the tail padding is not reproduced.
+    static size_t packetlength(uint32_t N, uint32_t L);
+    cpacketize();
+    ~cpacketize();
+    static void init(std::string address, bool noheader_, uint32_t nchannels_, uint32_t blocksize_);
+    static void cleanup();
+    void request_exit();
+    static int send();
+    int write(uint32_t channeln, uint32_t readcnt, int8_t *rp);
+    int write(uint32_t channeln, uint32_t readcnt, std::complex<float> *in);
+    int writedebug(uint32_t channeln, std::complex<float> p);
+    int notifysend();
+};
+#endif

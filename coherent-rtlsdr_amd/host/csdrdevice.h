@@ -1,0 +1,115 @@
+// csdrdevice.h -- the DSP-bearing part of the reference's device classes (include/csdrdevice.h:42-287,
+// src/csdrdevice.cc, src/crtlsdr.cc:173-223): per-channel block hand-off (read / consume / readcnt),
+// lag request handshake (requestfft / set_lag / get_lagp), and the per-row DSP members
+// convtofloat / est_phasecorrect / phasecorrect.  Tuner control (librtlsdr) is out of scope; the
+// concrete device here is a synthetic block source (csyntheticsdr) over host/csynth.c -- the
+// hardware-free csdrdevice the reference only stubs (class czmqsdr, include/csdrdevice.h:270-272).
+#ifndef CSDRDEVICEH
+#define CSDRDEVICEH
+#include <atomic>
+#include <chrono>
+#include <complex>
+#include <condition_variable>
+#include <cstdint>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "cdsp.h"
+#include "cpacketizer.h"
+extern "C" {
+#include "csynth.h"
+}
+
+typedef std::complex<float> lv_32fc_t;   // layout-identical to VOLK's type (src/ccoherent.cc:65)
+
+struct lagpoint {                        // include/csdrdevice.h:42-54
+    uint64_t ts;
+    float lag, mag, PAPR;
+    lagpoint() : ts(0), lag(0), mag(0), PAPR(0) {}
+};
+
+class csdrdevice {
+    uint32_t readcnt;
+protected:
+    std::mutex fftmtx;
+    std::condition_variable fftcv;
+    std::atomic<bool> lagrequested, lagready, synced, streaming;
+    std::complex<float> *sfloat;          // B complex, zero-initialised (src/csdrdevice.cc:43-45)
+    std::complex<float> phasecorr, phasecorrprev;
+    uint32_t asyncbufn, blocksize, samplerate, fcenter;
+    lagpoint lagp;
+    std::string devname;
+public:
+    cpacketize packetize;
+
+    virtual int8_t *read() = 0;                                   // include/csdrdevice.h:118
+    virtual void consume() = 0;
+    virtual uint32_t get_readcntbuf() = 0;
+    virtual const std::complex<float> *convtofloat() = 0;        // src/crtlsdr.cc:205-207 / :215-218
+    virtual const std::complex<float> *convtofloat(const std::complex<float> *) = 0;
+
+    std::complex<float> est_phasecorrect(const lv_32fc_t *ref);  // src/csdrdevice.cc:58-69
+    std::complex<float> get_phasecorrect() { return phasecorr; } // :76-78
+    std::complex<float> *phasecorrect();                          // :80-84
+    // the batched engine computes the EMA on the device; it mirrors the result back here
+    void set_phasecorrect(std::complex<float> p) { phasecorr = p; phasecorrprev = p; }
+
+    void requestfft() { lagready = false; lagrequested = true; } // include/csdrdevice.h:128
+    void requestfftblocking();                                    // :129-136
+    void set_lag(float lag, float mag);                           // :138-151
+    bool is_lagrequested() { return lagrequested; }
+    const std::complex<float> *get_sptr() { return sfloat; }
+    const lagpoint *get_lagp() { return &lagp; }
+    uint32_t get_blocksize() { return blocksize; }
+    float get_samplerate() { return samplerate; }
+    std::string get_devname() { return devname; }
+    inline uint32_t inc_readcnt() { return readcnt++; }
+    inline uint32_t get_readcnt() { return readcnt; }
+    inline bool is_ready() { return (readcnt >= asyncbufn) && streaming; } // include/csdrdevice.h:187-189
+    inline bool get_synchronized() { return synced; }
+    inline void set_synchronized(bool s) { synced = s; }
+
+    csdrdevice(uint32_t asyncbufn_, uint32_t blocksize_, uint32_t samplerate_, uint32_t fcenter_);
+    virtual ~csdrdevice();
+};
+
+// One synthetic "antenna array": generates whole blocks (all rows) once and hands rows to devices.
+class csynthsource {
+    csynth_params *params;
+    std::vector<int8_t> rows;
+    int nsig, L, block;
+public:
+    csynthsource(int nsig_, int L_, uint64_t seed, int dmax, bool locked);
+    ~csynthsource();
+    void advance();                                   // generate the next block
+    int8_t *row(int r) { return rows.data() + (size_t)r * 2 * L; }
+    const csynth_params *get_params() const { return params; }
+    int blockindex() const { return block; }
+    int get_L() const { return L; }
+};
+
+// signal channel (crtlsdr equivalent): samples land in sfloat[0..L)
+class csyntheticsdr : public csdrdevice {
+protected:
+    csynthsource *src;
+    int rowindex;
+    int8_t *cur;
+public:
+    csyntheticsdr(csynthsource *s, int row, uint32_t blocksize_, uint32_t samplerate_ = 2048000, uint32_t fcenter_ = 0);
+    int8_t *read() override;
+    void consume() override {}
+    uint32_t get_readcntbuf() override { return get_readcnt(); }
+    const std::complex<float> *convtofloat() override;
+    const std::complex<float> *convtofloat(const std::complex<float> *p) override;
+};
+
+// reference-noise channel (crefsdr, include/csdrdevice.h:274-287): samples land in sfloat[L..2L)
+class crefsdr : public csyntheticsdr {
+public:
+    crefsdr(csynthsource *s, uint32_t blocksize_) : csyntheticsdr(s, 0, blocksize_) { devname = "M REF"; }
+    const std::complex<float> *convtofloat() override;
+    const std::complex<float> *convtofloat(const std::complex<float> *p) override;
+};
+#endif
