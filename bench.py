@@ -250,7 +250,7 @@ def _committed_traffic(kernel):
         try:
             d = json.load(open(f))
             if kernel in d:
-                best = d[kernel]
+                best = d[kernel]["bytes_per_launch"] if isinstance(d[kernel], dict) else d[kernel]
         except Exception:
             pass
     return best

@@ -20,6 +20,15 @@ __device__ __forceinline__ int f32_to_i8(float x)
     return (int)rintf(r);
 }
 
+// same result for every non-NaN input, without the compare/select chain: clamp (v_med3), round to
+// nearest even (v_rndne), convert.  Used where the operand is finite by construction (K2b: int8
+// samples times a finite phasor).
+__device__ __forceinline__ int f32_to_i8_finite(float x)
+{
+    const float r = __fmul_rn(x, 127.0f);
+    return (int)rintf(__builtin_amdgcn_fmed3f(r, -128.0f, 127.0f));
+}
+
 // cdsp::scalarmul src/cdsp.cc:46-49: (ar*sr - ai*si) + j(ar*si + ai*sr), each op rounded once
 __device__ __forceinline__ float2 rot_rn(float2 a, float2 s)
 {

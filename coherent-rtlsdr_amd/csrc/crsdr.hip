@@ -660,19 +660,25 @@ extern "C" int crsdr_plan_submit_batch(crsdr_plan *p, const void *rows, int mem_
         HIP_TRY(hipEventRecord(p->ev_k1done[slot], S));
         p->k1done_valid[slot] = true;
     }
+    // 16-byte accesses need 16-byte aligned rows and matrix rows (always true for the plan's own
+    // buffers; a caller-bound packet or device input may only be 4-byte aligned -> word kernels)
+    const bool vec16 = ((uintptr_t)d_in % 16 == 0) && (d_stride % 16 == 0) && (((uintptr_t)p->d_packet + p->matrix_off) % 16 == 0) &&
+                       (p->packet_stride % 16 == 0 || nblocks == 1);
     // phase path: faithful mode does not depend on this batch's lags, digital mode does; either
     // way it follows K1 on the main stream (K1 is VALU bound, these two are the HBM-bound tail)
     if (aa.refnoise) {
         hipEvent_t *pe = prof_pair(p, CRSDR_KERNEL_PHASE_DOT);
         if (pe) HIP_TRY(hipEventRecord(pe[0], S));
-        hipLaunchKernelGGL(k_phase_dot, dim3(p->row_count, nblocks), dim3(kAlignThreads), 0, S, aa);
+        if (vec16) hipLaunchKernelGGL(k_phase_dot<true>, dim3(p->row_count, nblocks), dim3(kAlignThreads), 0, S, aa);
+        else hipLaunchKernelGGL(k_phase_dot<false>, dim3(p->row_count, nblocks), dim3(kAlignThreads), 0, S, aa);
         HIP_TRY(hipGetLastError());
         if (pe) HIP_TRY(hipEventRecord(pe[1], S));
     }
     {
         hipEvent_t *pe = prof_pair(p, CRSDR_KERNEL_ALIGN_QUANT);
         if (pe) HIP_TRY(hipEventRecord(pe[0], S));
-        hipLaunchKernelGGL(k_align_quant, dim3(1 + p->row_count, nblocks), dim3(kAlignThreads), 0, S, aa);
+        if (vec16) hipLaunchKernelGGL(k_align_quant<true>, dim3(1 + p->row_count, nblocks), dim3(kAlignThreads), 0, S, aa);
+        else hipLaunchKernelGGL(k_align_quant<false>, dim3(1 + p->row_count, nblocks), dim3(kAlignThreads), 0, S, aa);
         HIP_TRY(hipGetLastError());
         if (pe) HIP_TRY(hipEventRecord(pe[1], S));
     }

@@ -203,6 +203,35 @@ __device__ __forceinline__ uint32_t shifted_word(const uint32_t *__restrict__ s3
 // K2a: corr[t][row] = sum_n y[n] conj(r[n]) in exact integer arithmetic.  int8 products summed
 // exactly (|sum| <= 2^15 L): the fp32 value csdrdevice::est_phasecorrect (src/csdrdevice.cc:62)
 // accumulates is a rounding of this, scaled by 1/127^2 -- and the phasor is scale-invariant.
+// 16 bytes = 8 complex samples of the row shifted by d, starting at output sample 8*i.  Interior
+// vectors are ONE 16-byte load at a 2-byte-aligned address (gfx950 global loads need no natural
+// alignment); the at most two vectors that straddle [0,L) fall back to word-wise assembly.
+struct __attribute__((packed, aligned(2))) u4_unaligned { uint32_t x, y, z, w; };
+__device__ __forceinline__ uint4 shifted_vec(const int8_t *__restrict__ srow, int i, int d, int L, uint32_t xor80)
+{
+    const int m0 = 8 * i + d;
+    uint4 v;
+    if (m0 >= 0 && m0 + 8 <= L) {
+        const u4_unaligned u = *reinterpret_cast<const u4_unaligned *>(srow + 2 * (ptrdiff_t)m0);
+        v = make_uint4(u.x ^ xor80, u.y ^ xor80, u.z ^ xor80, u.w ^ xor80);
+    } else {
+        const uint32_t *s32 = reinterpret_cast<const uint32_t *>(srow);
+        v = make_uint4(shifted_word(s32, 4 * i, d, L, xor80), shifted_word(s32, 4 * i + 1, d, L, xor80),
+                       shifted_word(s32, 4 * i + 2, d, L, xor80), shifted_word(s32, 4 * i + 3, d, L, xor80));
+    }
+    return v;
+}
+
+__device__ __forceinline__ void dot_word(uint32_t s, uint32_t r, int &re, int &im)
+{
+    // bytes of a word: [I0 Q0 I1 Q1]
+    const uint32_t sw = ((s >> 8) & 0x00FF00FFu) | ((s << 8) & 0xFF00FF00u);     // [Q0 I0 Q1 I1]
+    re = __builtin_amdgcn_sdot4((int)s, (int)r, re, false);                       // I.rI + Q.rQ
+    im = __builtin_amdgcn_sdot4((int)sw, (int)(r & 0x00FF00FFu), im, false);      // + Q.rI
+    im -= __builtin_amdgcn_sdot4((int)sw, (int)(r & 0xFF00FF00u), 0, false);      // - I.rQ
+}
+
+template <bool VEC>
 __global__ __launch_bounds__(kAlignThreads) void k_phase_dot(AlignArgs a)
 {
     __shared__ long long sred[2 * (kAlignThreads / 64)];
@@ -213,15 +242,25 @@ __global__ __launch_bounds__(kAlignThreads) void k_phase_dot(AlignArgs a)
     const uint32_t *s32 = reinterpret_cast<const uint32_t *>(blk + (size_t)row * B);
     const uint32_t *r32 = reinterpret_cast<const uint32_t *>(blk);
     const int d = align_shift(a, row, t);
-    // bytes of a word: [I0 Q0 I1 Q1]; int32 partials are safe (<= 2^16 per word, <= 2^13 words per thread)
+    // int32 partials are safe (<= 2^16 per word, <= 2^13 words per thread)
     int re = 0, im = 0;
-    for (int i = tid; i < B / 4; i += kAlignThreads) {
-        const uint32_t s = (d == 0) ? (s32[i] ^ a.xor80) : shifted_word(s32, i, d, L, a.xor80);
-        const uint32_t r = r32[i] ^ a.xor80;
-        const uint32_t sw = ((s >> 8) & 0x00FF00FFu) | ((s << 8) & 0xFF00FF00u);     // [Q0 I0 Q1 I1]
-        re = __builtin_amdgcn_sdot4((int)s, (int)r, re, false);                       // I.rI + Q.rQ
-        im = __builtin_amdgcn_sdot4((int)sw, (int)(r & 0x00FF00FFu), im, false);      // + Q.rI
-        im -= __builtin_amdgcn_sdot4((int)sw, (int)(r & 0xFF00FF00u), 0, false);      // - I.rQ
+    if constexpr (VEC) {
+        const int8_t *srow = blk + (size_t)row * B;
+        const uint4 *r128 = reinterpret_cast<const uint4 *>(blk);
+#pragma unroll 4
+        for (int i = tid; i < B / 16; i += kAlignThreads) {
+            const uint4 sv = shifted_vec(srow, i, d, L, a.xor80);
+            const uint4 rv = r128[i];
+            dot_word(sv.x, rv.x ^ a.xor80, re, im);
+            dot_word(sv.y, rv.y ^ a.xor80, re, im);
+            dot_word(sv.z, rv.z ^ a.xor80, re, im);
+            dot_word(sv.w, rv.w ^ a.xor80, re, im);
+        }
+    } else {
+        for (int i = tid; i < B / 4; i += kAlignThreads) {
+            const uint32_t s = (d == 0) ? (s32[i] ^ a.xor80) : shifted_word(s32, i, d, L, a.xor80);
+            dot_word(s, r32[i] ^ a.xor80, re, im);
+        }
     }
     long long acc_re = re, acc_im = im;
 #pragma unroll
@@ -242,6 +281,17 @@ __global__ __launch_bounds__(kAlignThreads) void k_phase_dot(AlignArgs a)
 // K2b: grid.x = 1 + owned signal rows; block x = 0 writes the packet header and copies the raw
 // reference row (cpacketize::write(int8*) src/cpacketizer.cc:137-156); block x >= 1 handles row
 // row_begin + x - 1 of batch block t = blockIdx.y.
+// rotate + quantise the two samples of one word: csdrdevice::phasecorrect (src/csdrdevice.cc:80-84)
+// then cdsp::convto8bit (src/cdsp.cc:51-54), single-rounding ops in the oracle's order
+__device__ __forceinline__ uint32_t rotq_word(uint32_t s, float2 p)
+{
+    const float2 y0 = rot_rn(make_float2(i8_to_f32(sext8(s, 0)), i8_to_f32(sext8(s, 1))), p);
+    const float2 y1 = rot_rn(make_float2(i8_to_f32(sext8(s, 2)), i8_to_f32(sext8(s, 3))), p);
+    return (uint32_t)(f32_to_i8_finite(y0.x) & 0xFF) | ((uint32_t)(f32_to_i8_finite(y0.y) & 0xFF) << 8) |
+           ((uint32_t)(f32_to_i8_finite(y1.x) & 0xFF) << 16) | ((uint32_t)(f32_to_i8_finite(y1.y) & 0xFF) << 24);
+}
+
+template <bool VEC>
 __global__ __launch_bounds__(kAlignThreads) void k_align_quant(AlignArgs a)
 {
     __shared__ float2 sp;
@@ -256,9 +306,18 @@ __global__ __launch_bounds__(kAlignThreads) void k_align_quant(AlignArgs a)
         const uint32_t seq = a.seq + (uint32_t)t;
         if (tid == 0) { h[0] = seq; h[1] = (uint32_t)a.nrows; h[2] = (uint32_t)L; h[3] = 0u; }
         for (int r = tid; r < a.nrows; r += kAlignThreads) h[4 + r] = a.readcnt ? a.readcnt[(size_t)t * a.nrows + r] : seq;
-        const uint32_t *src = reinterpret_cast<const uint32_t *>(blk);
-        uint32_t *dst = reinterpret_cast<uint32_t *>(packet + moff);
-        for (int i = tid; i < B / 4; i += kAlignThreads) dst[i] = src[i] ^ a.xor80;
+        if constexpr (VEC) {
+            const uint4 *src = reinterpret_cast<const uint4 *>(blk);
+            uint4 *dst = reinterpret_cast<uint4 *>(packet + moff);
+            for (int i = tid; i < B / 16; i += kAlignThreads) {
+                const uint4 v = src[i];
+                dst[i] = make_uint4(v.x ^ a.xor80, v.y ^ a.xor80, v.z ^ a.xor80, v.w ^ a.xor80);
+            }
+        } else {
+            const uint32_t *src = reinterpret_cast<const uint32_t *>(blk);
+            uint32_t *dst = reinterpret_cast<uint32_t *>(packet + moff);
+            for (int i = tid; i < B / 4; i += kAlignThreads) dst[i] = src[i] ^ a.xor80;
+        }
         return;
     }
     const int row = a.row_begin + (int)blockIdx.x - 1;
@@ -291,13 +350,20 @@ __global__ __launch_bounds__(kAlignThreads) void k_align_quant(AlignArgs a)
 
     // csdrdevice::phasecorrect (src/csdrdevice.cc:80-84) + cpacketize::write(complex<float>*)
     // (src/cpacketizer.cc:158-172): y * p, x127, saturate, round-half-even, int8 at the row offset
-    uint32_t *o32 = reinterpret_cast<uint32_t *>(packet + moff + (size_t)row * B);
-    for (int i = tid; i < B / 4; i += kAlignThreads) {
-        const uint32_t s = (d == 0) ? (s32[i] ^ a.xor80) : shifted_word(s32, i, d, L, a.xor80);
-        const float2 y0 = rot_rn(make_float2(i8_to_f32(sext8(s, 0)), i8_to_f32(sext8(s, 1))), p);
-        const float2 y1 = rot_rn(make_float2(i8_to_f32(sext8(s, 2)), i8_to_f32(sext8(s, 3))), p);
-        o32[i] = (uint32_t)(f32_to_i8(y0.x) & 0xFF) | ((uint32_t)(f32_to_i8(y0.y) & 0xFF) << 8) |
-                 ((uint32_t)(f32_to_i8(y1.x) & 0xFF) << 16) | ((uint32_t)(f32_to_i8(y1.y) & 0xFF) << 24);
+    if constexpr (VEC) {
+        const int8_t *srow = blk + (size_t)row * B;
+        uint4 *o128 = reinterpret_cast<uint4 *>(packet + moff + (size_t)row * B);
+#pragma unroll 4
+        for (int i = tid; i < B / 16; i += kAlignThreads) {
+            const uint4 sv = shifted_vec(srow, i, d, L, a.xor80);
+            o128[i] = make_uint4(rotq_word(sv.x, p), rotq_word(sv.y, p), rotq_word(sv.z, p), rotq_word(sv.w, p));
+        }
+    } else {
+        uint32_t *o32 = reinterpret_cast<uint32_t *>(packet + moff + (size_t)row * B);
+        for (int i = tid; i < B / 4; i += kAlignThreads) {
+            const uint32_t s = (d == 0) ? (s32[i] ^ a.xor80) : shifted_word(s32, i, d, L, a.xor80);
+            o32[i] = rotq_word(s, p);
+        }
     }
 }
 
