@@ -102,7 +102,20 @@ static int make_twiddles14(float2 **d_twA, float2 **d_twB)
     return CRSDR_OK;
 }
 
-constexpr int kMinLog2 = 4, kMaxLog2 = 14; // LDS-resident transform sizes: 16 .. 16384 points
+// forward table W_n^(k * step), k < count
+static int make_twiddle_table(double n, size_t count, size_t step, float2 **d)
+{
+    std::vector<float2> h(count);
+    for (size_t k = 0; k < count; ++k) {
+        double a = 2.0 * M_PI * (double)(k * step) / n;
+        h[k] = make_float2((float)std::cos(a), (float)(-std::sin(a)));
+    }
+    HIP_TRY(hipMalloc((void **)d, sizeof(float2) * count));
+    HIP_TRY(hipMemcpy(*d, h.data(), sizeof(float2) * count, hipMemcpyHostToDevice));
+    return CRSDR_OK;
+}
+
+constexpr int kMinLog2 = 4, kMaxLog2 = 14, kMaxLog2Plan = 22; // LDS-resident sizes; long-block plans up to 2^22 // LDS-resident transform sizes: 16 .. 16384 points
 
 template <int LOG2N>
 static constexpr size_t fft_lds_bytes() { return sizeof(float2) * ((size_t)1 << LOG2N) + 256; }
@@ -158,6 +171,51 @@ static hipError_t launch_op_fft(hipStream_t s, int howmany, float2 *out, const f
     hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(kern, dim3(howmany), dim3(FftGeom<LOG2N>::THREADS), lds, s, out, in, tw);
+    return hipGetLastError();
+}
+
+// ---- long-block path (B = N1 x 16384) ----------------------------------------------------------------
+#define CRSDR_DISPATCH_N1(l2, CALL)                                                     \
+    [&]() -> hipError_t {                                                               \
+        switch (l2) {                                                                   \
+        case 1: { constexpr int LG = 1; return CALL; }                                  \
+        case 2: { constexpr int LG = 2; return CALL; }                                  \
+        case 3: { constexpr int LG = 3; return CALL; }                                  \
+        case 4: { constexpr int LG = 4; return CALL; }                                  \
+        case 5: { constexpr int LG = 5; return CALL; }                                  \
+        case 6: { constexpr int LG = 6; return CALL; }                                  \
+        case 7: { constexpr int LG = 7; return CALL; }                                  \
+        case 8: { constexpr int LG = 8; return CALL; }                                  \
+        default: return hipErrorInvalidValue;                                           \
+        }                                                                               \
+    }()
+
+template <int LOG2N1, bool IS_REF>
+static hipError_t launch_long_fwd_cols(hipStream_t s, int nrows_launch, const int8_t *rows, int row_begin, uint32_t xor80,
+                                       const lb::LongTw &tw, float2 *Y)
+{
+    auto kern = lb::k_long_fwd_cols<LOG2N1, IS_REF>;
+    hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lb::LDS_BYTES);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(kern, dim3(1 << LOG2N1, nrows_launch), dim3(lb::THREADS), lb::LDS_BYTES, s, rows, row_begin, xor80, tw, Y);
+    return hipGetLastError();
+}
+template <bool IS_REF>
+static hipError_t launch_long_rows(hipStream_t s, int n1, int nrows_launch, float2 *Y, const lb::LongTw &tw, float2 *refspec)
+{
+    auto kern = lb::k_long_rows<IS_REF>;
+    hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lb::LDS_BYTES);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(kern, dim3(n1, nrows_launch), dim3(lb::THREADS), lb::LDS_BYTES, s, Y, tw, refspec);
+    return hipGetLastError();
+}
+template <int LOG2N1>
+static hipError_t launch_long_inv_cols(hipStream_t s, int nrows_launch, const float2 *Z, const lb::LongTw &tw, lb::LongPartial *part)
+{
+    auto kern = lb::k_long_inv_cols<LOG2N1>;
+    hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lb::LDS_BYTES);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(kern, dim3(1 << LOG2N1, nrows_launch), dim3(lb::THREADS), lb::LDS_BYTES, s, Z, tw, part);
     return hipGetLastError();
 }
 
@@ -360,6 +418,11 @@ struct crsdr_plan {
     long long *d_corr = nullptr;       // [T][nrows][2]
     int phase_cur = 0;
     int last_nblocks = 0;
+    // long-block path (B > 16384): B = N1 x 16384
+    bool longblock = false;
+    int log2n1 = 0;
+    float2 *d_wc = nullptr, *d_wf = nullptr, *d_tw1 = nullptr, *d_Y = nullptr, *d_Yref = nullptr;
+    lb::LongPartial *d_part = nullptr;
     // pinned staging ring for the small per-batch host arrays
     uint32_t *h_readcnt = nullptr;
     uint8_t *h_mask = nullptr;
@@ -414,8 +477,18 @@ static int plan_alloc(crsdr_plan *p)
     for (int i = 0; i < kStageSlots; ++i) HIP_TRY(hipEventCreateWithFlags(&p->ev_stage[i], hipEventDisableTiming));
     HIP_TRY(hipEventCreate(&p->ev_start));
     HIP_TRY(hipEventCreate(&p->ev_stop));
-    { int rc = make_twiddles(p->B, &p->d_tw); if (rc) return rc; }
+    { int rc = make_twiddles(p->longblock ? lb::N2 : p->B, &p->d_tw); if (rc) return rc; }
     if (p->log2n == 14) { int rc = make_twiddles14(&p->d_twA, &p->d_twB); if (rc) return rc; }
+    if (p->longblock) {
+        const size_t Bz = (size_t)p->B, n1 = Bz >> lb::LOG2N2;
+        int rc;
+        if ((rc = make_twiddle_table((double)Bz, Bz >> lb::FBITS, (size_t)1 << lb::FBITS, &p->d_wc))) return rc;
+        if ((rc = make_twiddle_table((double)Bz, (size_t)1 << lb::FBITS, 1, &p->d_wf))) return rc;
+        if ((rc = make_twiddle_table((double)n1, n1, 1, &p->d_tw1))) return rc;
+        HIP_TRY(hipMalloc((void **)&p->d_Y, sizeof(float2) * Bz * (size_t)p->row_count));
+        HIP_TRY(hipMalloc((void **)&p->d_Yref, sizeof(float2) * Bz));
+        HIP_TRY(hipMalloc((void **)&p->d_part, sizeof(lb::LongPartial) * n1 * (size_t)p->row_count));
+    }
     const size_t n = (size_t)p->nrows, T = (size_t)p->max_batch;
     const size_t rowbytes = n * (size_t)p->B;
     for (int i = 0; i < 2; ++i) HIP_TRY(hipMalloc((void **)&p->d_refspec[i], sizeof(float2) * (size_t)p->B * T));
@@ -451,7 +524,7 @@ static void plan_free(crsdr_plan *p)
     (void)hipSetDevice(p->device);
     if (p->own_stream) (void)hipStreamSynchronize(p->own_stream);
     if (p->aux) (void)hipStreamSynchronize(p->aux);
-    void *bufs[] = {p->d_tw, p->d_twA, p->d_twB, p->d_refspec[0], p->d_refspec[1], p->d_rows, p->d_packet_alloc, p->d_readcnt,
+    void *bufs[] = {p->d_wc, p->d_wf, p->d_tw1, p->d_Y, p->d_Yref, p->d_part, p->d_tw, p->d_twA, p->d_twB, p->d_refspec[0], p->d_refspec[1], p->d_rows, p->d_packet_alloc, p->d_readcnt,
                     p->d_mask, p->d_lag, p->d_mag, p->d_frac, p->d_phasor, p->d_corr, p->d_lag_state, p->d_mag_state,
                     p->d_frac_state, p->d_phase_state[0], p->d_phase_state[1]};
     for (void *b : bufs) if (b) (void)hipFree(b);
@@ -472,8 +545,8 @@ extern "C" int crsdr_plan_create(crsdr_plan **plan, const crsdr_plan_desc *desc)
     *plan = nullptr;
     const int l2 = ilog2_exact(desc->blocksize);
     if (desc->nrows < 2) return fail(CRSDR_EINVAL, "plan_create: nrows = %d (need the ref row and >= 1 signal row)", desc->nrows);
-    if (l2 < kMinLog2 || l2 > kMaxLog2)
-        return fail(CRSDR_EINVAL, "plan_create: blocksize = %d unsupported (power of two in [16, 16384])", desc->blocksize);
+    if (l2 < kMinLog2 || l2 > kMaxLog2Plan)
+        return fail(CRSDR_EINVAL, "plan_create: blocksize = %d unsupported (power of two in [16, 4194304])", desc->blocksize);
     if (desc->mode != CRSDR_MODE_FAITHFUL && desc->mode != CRSDR_MODE_DIGITAL)
         return fail(CRSDR_EINVAL, "plan_create: mode = %d", desc->mode);
     const int rb = desc->row_begin ? desc->row_begin : 1;
@@ -482,6 +555,7 @@ extern "C" int crsdr_plan_create(crsdr_plan **plan, const crsdr_plan_desc *desc)
         return fail(CRSDR_EINVAL, "plan_create: slab [%d,%d) outside signal rows [1,%d)", rb, rb + rc_rows, desc->nrows);
     const int mb = desc->max_batch ? desc->max_batch : 1;
     if (mb < 1 || mb > kMaxBatch) return fail(CRSDR_EINVAL, "plan_create: max_batch = %d (1..%d)", mb, kMaxBatch);
+    if (l2 > kMaxLog2 && mb != 1) return fail(CRSDR_EINVAL, "plan_create: long blocks (blocksize > 16384) take max_batch = 1");
     { int rc = require_device(); if (rc) return rc; }
     int ndev = 0;
     (void)crsdr_device_count(&ndev);
@@ -491,6 +565,7 @@ extern "C" int crsdr_plan_create(crsdr_plan **plan, const crsdr_plan_desc *desc)
     if (!p) return fail(CRSDR_ENOMEM, "plan_create: out of host memory");
     p->nrows = desc->nrows; p->B = desc->blocksize; p->L = p->B / 2; p->log2n = l2; p->mode = desc->mode;
     p->device = desc->device; p->row_begin = rb; p->row_count = rc_rows; p->max_batch = mb;
+    p->longblock = l2 > kMaxLog2; p->log2n1 = p->longblock ? l2 - lb::LOG2N2 : 0;
     p->matrix_off = 16 + 4 * (size_t)p->nrows;
     p->packet_bytes = p->matrix_off + (size_t)p->nrows * (size_t)p->B;
     int rc = plan_alloc(p);
@@ -631,7 +706,29 @@ extern "C" int crsdr_plan_submit_batch(crsdr_plan *p, const void *rows, int mem_
     aa.xcorr_ran = any_lag ? 1 : 0;
     aa.seq = seq; aa.xor80 = xor80;
 
-    if (any_lag) {
+    if (any_lag && p->longblock) {
+        // B = N1 x 16384: column FFTs -> row FFTs (x conj ref, inverse) -> inverse column FFTs + argmax -> finalize
+        lb::LongTw tw{p->d_wc, p->d_wf, p->d_tw1, p->d_tw, (uint32_t)(p->B - 1)};
+        const int n1 = 1 << p->log2n1, l1 = p->log2n1;
+        hipEvent_t *pe0 = prof_pair(p, CRSDR_KERNEL_REF_SPECTRUM);
+        if (pe0) HIP_TRY(hipEventRecord(pe0[0], S));
+        HIP_TRY(CRSDR_DISPATCH_N1(l1, (launch_long_fwd_cols<LG, true>(S, 1, d_in, 0, xor80, tw, p->d_Yref))));
+        HIP_TRY(launch_long_rows<true>(S, n1, 1, p->d_Yref, tw, p->d_refspec[0]));
+        if (pe0) HIP_TRY(hipEventRecord(pe0[1], S));
+        XcorrArgs xa;
+        xa.rows = d_in; xa.block_stride = d_stride; xa.refspec = p->d_refspec[0]; xa.lag_mask = d_mask;
+        xa.row_begin = p->row_begin; xa.nrows = p->nrows; xa.nblocks = 1; xa.xor80 = xor80;
+        xa.lag = p->d_lag; xa.mag = p->d_mag; xa.frac = p->d_frac;
+        xa.lag_state = p->d_lag_state; xa.mag_state = p->d_mag_state; xa.frac_state = p->d_frac_state;
+        hipEvent_t *pe1 = prof_pair(p, CRSDR_KERNEL_XCORR_LAG);
+        if (pe1) HIP_TRY(hipEventRecord(pe1[0], S));
+        HIP_TRY(CRSDR_DISPATCH_N1(l1, (launch_long_fwd_cols<LG, false>(S, p->row_count, d_in, p->row_begin, xor80, tw, p->d_Y))));
+        HIP_TRY(launch_long_rows<false>(S, n1, p->row_count, p->d_Y, tw, p->d_refspec[0]));
+        HIP_TRY(CRSDR_DISPATCH_N1(l1, (launch_long_inv_cols<LG>(S, p->row_count, p->d_Y, tw, p->d_part))));
+        hipLaunchKernelGGL(lb::k_long_finalize, dim3(p->row_count), dim3(256), 0, S, p->d_Y, p->d_part, tw, n1, xa);
+        HIP_TRY(hipGetLastError());
+        if (pe1) HIP_TRY(hipEventRecord(pe1[1], S));
+    } else if (any_lag) {
         const int slot = (p->slot ^= 1);
         // K0 on the aux stream: with resident input it overlaps the previous batch's K1 / K2
         if (!input_ready) {
@@ -666,19 +763,21 @@ extern "C" int crsdr_plan_submit_batch(crsdr_plan *p, const void *rows, int mem_
                        (p->packet_stride % 16 == 0 || nblocks == 1);
     // phase path: faithful mode does not depend on this batch's lags, digital mode does; either
     // way it follows K1 on the main stream (K1 is VALU bound, these two are the HBM-bound tail)
+    const int chunks = p->B > 16384 ? p->B / 16384 : 1; // long rows: 16 KiB of the row per workgroup
     if (aa.refnoise) {
         hipEvent_t *pe = prof_pair(p, CRSDR_KERNEL_PHASE_DOT);
         if (pe) HIP_TRY(hipEventRecord(pe[0], S));
-        if (vec16) hipLaunchKernelGGL(k_phase_dot<true>, dim3(p->row_count, nblocks), dim3(kAlignThreads), 0, S, aa);
-        else hipLaunchKernelGGL(k_phase_dot<false>, dim3(p->row_count, nblocks), dim3(kAlignThreads), 0, S, aa);
+        if (chunks > 1) HIP_TRY(hipMemsetAsync(p->d_corr, 0, sizeof(long long) * 2 * n * T, S)); // atomically accumulated
+        if (vec16) hipLaunchKernelGGL(k_phase_dot<true>, dim3(p->row_count, nblocks, chunks), dim3(kAlignThreads), 0, S, aa);
+        else hipLaunchKernelGGL(k_phase_dot<false>, dim3(p->row_count, nblocks, chunks), dim3(kAlignThreads), 0, S, aa);
         HIP_TRY(hipGetLastError());
         if (pe) HIP_TRY(hipEventRecord(pe[1], S));
     }
     {
         hipEvent_t *pe = prof_pair(p, CRSDR_KERNEL_ALIGN_QUANT);
         if (pe) HIP_TRY(hipEventRecord(pe[0], S));
-        if (vec16) hipLaunchKernelGGL(k_align_quant<true>, dim3(1 + p->row_count, nblocks), dim3(kAlignThreads), 0, S, aa);
-        else hipLaunchKernelGGL(k_align_quant<false>, dim3(1 + p->row_count, nblocks), dim3(kAlignThreads), 0, S, aa);
+        if (vec16) hipLaunchKernelGGL(k_align_quant<true>, dim3(1 + p->row_count, nblocks, chunks), dim3(kAlignThreads), 0, S, aa);
+        else hipLaunchKernelGGL(k_align_quant<false>, dim3(1 + p->row_count, nblocks, chunks), dim3(kAlignThreads), 0, S, aa);
         HIP_TRY(hipGetLastError());
         if (pe) HIP_TRY(hipEventRecord(pe[1], S));
     }

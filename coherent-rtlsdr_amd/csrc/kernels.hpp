@@ -22,6 +22,7 @@
 #include "fft_lds.hpp"
 #include "plan_args.hpp"
 #include "xcorr14.hpp"
+#include "longblock.hpp"
 #include <stdint.h>
 
 namespace crsdr {
@@ -244,11 +245,14 @@ __global__ __launch_bounds__(kAlignThreads) void k_phase_dot(AlignArgs a)
     const int d = align_shift(a, row, t);
     // int32 partials are safe (<= 2^16 per word, <= 2^13 words per thread)
     int re = 0, im = 0;
+    // long rows are split over grid.z chunks (one chunk for B <= 16 KiB)
+    const int nchunk = gridDim.z, v_lo = (int)(((long long)(B / 16) * blockIdx.z) / nchunk),
+              v_hi = (int)(((long long)(B / 16) * (blockIdx.z + 1)) / nchunk);
     if constexpr (VEC) {
         const int8_t *srow = blk + (size_t)row * B;
         const uint4 *r128 = reinterpret_cast<const uint4 *>(blk);
 #pragma unroll 4
-        for (int i = tid; i < B / 16; i += kAlignThreads) {
+        for (int i = v_lo + tid; i < v_hi; i += kAlignThreads) {
             const uint4 sv = shifted_vec(srow, i, d, L, a.xor80);
             const uint4 rv = r128[i];
             dot_word(sv.x, rv.x ^ a.xor80, re, im);
@@ -257,7 +261,7 @@ __global__ __launch_bounds__(kAlignThreads) void k_phase_dot(AlignArgs a)
             dot_word(sv.w, rv.w ^ a.xor80, re, im);
         }
     } else {
-        for (int i = tid; i < B / 4; i += kAlignThreads) {
+        for (int i = 4 * v_lo + tid; i < 4 * v_hi; i += kAlignThreads) {
             const uint32_t s = (d == 0) ? (s32[i] ^ a.xor80) : shifted_word(s32, i, d, L, a.xor80);
             dot_word(s, r32[i] ^ a.xor80, re, im);
         }
@@ -273,8 +277,12 @@ __global__ __launch_bounds__(kAlignThreads) void k_phase_dot(AlignArgs a)
     if (tid == 0) {
         long long sr = 0, si = 0;
         for (int w = 0; w < kAlignThreads / 64; ++w) { sr += sred[2 * w]; si += sred[2 * w + 1]; }
-        a.corr[2 * ((size_t)t * a.nrows + row)] = sr;
-        a.corr[2 * ((size_t)t * a.nrows + row) + 1] = si;
+        long long *c = a.corr + 2 * ((size_t)t * a.nrows + row);
+        if (nchunk == 1) { c[0] = sr; c[1] = si; }
+        else { // integer partial sums: the order of the adds does not matter (corr zeroed by the host)
+            atomicAdd(reinterpret_cast<unsigned long long *>(c), (unsigned long long)sr);
+            atomicAdd(reinterpret_cast<unsigned long long *>(c + 1), (unsigned long long)si);
+        }
     }
 }
 
@@ -300,23 +308,27 @@ __global__ __launch_bounds__(kAlignThreads) void k_align_quant(AlignArgs a)
     const size_t moff = 16 + 4 * (size_t)a.nrows;
     const int8_t *blk = a.rows + (size_t)t * a.block_stride;
     int8_t *packet = a.packet + (size_t)t * a.packet_stride;
+    const int nchunk = gridDim.z, v_lo = (int)(((long long)(B / 16) * blockIdx.z) / nchunk),
+              v_hi = (int)(((long long)(B / 16) * (blockIdx.z + 1)) / nchunk);
     if (blockIdx.x == 0) {
         // header hdr0{globalseqn,N,L,unused} src/cpacketizer.cc:112-116 and readcnt words :142,163
         uint32_t *h = reinterpret_cast<uint32_t *>(packet);
         const uint32_t seq = a.seq + (uint32_t)t;
-        if (tid == 0) { h[0] = seq; h[1] = (uint32_t)a.nrows; h[2] = (uint32_t)L; h[3] = 0u; }
-        for (int r = tid; r < a.nrows; r += kAlignThreads) h[4 + r] = a.readcnt ? a.readcnt[(size_t)t * a.nrows + r] : seq;
+        if (blockIdx.z == 0) {
+            if (tid == 0) { h[0] = seq; h[1] = (uint32_t)a.nrows; h[2] = (uint32_t)L; h[3] = 0u; }
+            for (int r = tid; r < a.nrows; r += kAlignThreads) h[4 + r] = a.readcnt ? a.readcnt[(size_t)t * a.nrows + r] : seq;
+        }
         if constexpr (VEC) {
             const uint4 *src = reinterpret_cast<const uint4 *>(blk);
             uint4 *dst = reinterpret_cast<uint4 *>(packet + moff);
-            for (int i = tid; i < B / 16; i += kAlignThreads) {
+            for (int i = v_lo + tid; i < v_hi; i += kAlignThreads) {
                 const uint4 v = src[i];
                 dst[i] = make_uint4(v.x ^ a.xor80, v.y ^ a.xor80, v.z ^ a.xor80, v.w ^ a.xor80);
             }
         } else {
             const uint32_t *src = reinterpret_cast<const uint32_t *>(blk);
             uint32_t *dst = reinterpret_cast<uint32_t *>(packet + moff);
-            for (int i = tid; i < B / 4; i += kAlignThreads) dst[i] = src[i] ^ a.xor80;
+            for (int i = 4 * v_lo + tid; i < 4 * v_hi; i += kAlignThreads) dst[i] = src[i] ^ a.xor80;
         }
         return;
     }
@@ -341,8 +353,10 @@ __global__ __launch_bounds__(kAlignThreads) void k_align_quant(AlignArgs a)
                 }
             }
         }
-        a.phasor[(size_t)t * a.nrows + row] = p;       // get_phasecorrect() after block t
-        if (t == a.nblocks - 1) a.phase_out[row] = p;  // state carried to the next batch
+        if (blockIdx.z == 0) {
+            a.phasor[(size_t)t * a.nrows + row] = p;       // get_phasecorrect() after block t
+            if (t == a.nblocks - 1) a.phase_out[row] = p;  // state carried to the next batch
+        }
         sp = p;
     }
     __syncthreads();
@@ -354,13 +368,13 @@ __global__ __launch_bounds__(kAlignThreads) void k_align_quant(AlignArgs a)
         const int8_t *srow = blk + (size_t)row * B;
         uint4 *o128 = reinterpret_cast<uint4 *>(packet + moff + (size_t)row * B);
 #pragma unroll 4
-        for (int i = tid; i < B / 16; i += kAlignThreads) {
+        for (int i = v_lo + tid; i < v_hi; i += kAlignThreads) {
             const uint4 sv = shifted_vec(srow, i, d, L, a.xor80);
             o128[i] = make_uint4(rotq_word(sv.x, p), rotq_word(sv.y, p), rotq_word(sv.z, p), rotq_word(sv.w, p));
         }
     } else {
         uint32_t *o32 = reinterpret_cast<uint32_t *>(packet + moff + (size_t)row * B);
-        for (int i = tid; i < B / 4; i += kAlignThreads) {
+        for (int i = 4 * v_lo + tid; i < 4 * v_hi; i += kAlignThreads) {
             const uint32_t s = (d == 0) ? (s32[i] ^ a.xor80) : shifted_word(s32, i, d, L, a.xor80);
             o32[i] = rotq_word(s, p);
         }

@@ -1,0 +1,261 @@
+// longblock.hpp -- cross-correlation for blocks longer than the LDS-resident limit
+// (B = 2^15 .. 2^22 complex FFT points per row; BASELINE config 5: L = 2^20, B = 2^21).
+//
+// A row no longer fits in one CU's LDS (B = 2^21 is 16 MiB of cf32), so the B-point transform is
+// split  B = N1 x N2,  N2 = 16384 (the LDS-resident size),  N1 = B / 16384 in {2..256}:
+//
+//   x[n1 N2 + n2] --A: N1-point column FFTs, x W_B^(n2 k1)--> Y[k1][n2]
+//                 --B: 16384-point row FFTs (x conj(ref), inverse)--> Z[k1][n2]
+//                 --C: x conj W_B^(n2 k1), inverse N1-point column FFTs, |.|^2, argmax--> partials
+//                 --D: reduce partials, parabolic neighbours from N1-term sums--> lag, mag, frac
+//
+// Every pass streams the row through HBM once with >= 256-byte contiguous segments (A reads the
+// int8 input directly, zero half never read; C never writes the correlation back).  This is the
+// HBM-streaming regime of the path: ~64 MiB of traffic per 2 MiB int8 row.
+// Reference semantics are unchanged: fftwf_plan_many_dft of length B (src/ccoherent.cc:78-93),
+// conjugate multiply (:177-179), |.|^2 and first-maximum argmax (:185-192), lag/mag (:204,:232).
+#pragma once
+#include "arith.hpp"
+#include "fft_lds.hpp"
+#include "plan_args.hpp"
+#include <stdint.h>
+
+namespace crsdr {
+namespace lb {
+
+constexpr int LOG2N2 = 14, N2 = 1 << LOG2N2, THREADS = 1024, TILE = 16384; // elements per LDS tile
+constexpr int FBITS = 11;                                                    // fine twiddle table: 2^11 entries
+constexpr size_t LDS_BYTES = sizeof(float2) * TILE + 512;
+
+struct LongTw {
+    const float2 *wc;  // W_B^(i << FBITS), i < B >> FBITS      (coarse)
+    const float2 *wf;  // W_B^j,            j < 1 << FBITS      (fine)
+    const float2 *tw1; // W_N1^k, k < N1                        (column transforms)
+    const float2 *tw2; // W_16384^k, k < 16384                  (row transforms)
+    uint32_t bmask;    // B - 1
+};
+
+// forward twiddle W_B^m (m taken mod B), two-level table: one product, ~1 ulp
+__device__ __forceinline__ float2 tw_big(const LongTw &t, uint32_t m)
+{
+    m &= t.bmask;
+    return cmul(t.wc[m >> FBITS], t.wf[m & ((1u << FBITS) - 1)]);
+}
+
+template <int LOG2N1>
+__device__ __forceinline__ int rev_n1(int j) { return digit_reverse<LOG2N1>(j); }
+
+// C = TILE / N1 independent N1-point DIF transforms along the rows of an LDS tile laid out
+// [n1][C] (same orientation as global memory, lanes run along the C columns: conflict-free).
+// Leaves X_col[rev(j)] in tile row j.  Caller syncs before; this syncs after every pass.
+template <int LOG2N1, int DIR, int P = 0>
+__device__ __forceinline__ void col_fft(float2 *T, const float2 *__restrict__ tw1, int tid)
+{
+    using G = FftGeom<LOG2N1>;
+    if constexpr (P < G::NPASS) {
+        constexpr int LOG2C = LOG2N2 - LOG2N1, C = 1 << LOG2C;
+        constexpr int LR = G::log2r(P), R = 1 << LR, LM = G::log2m(P), M = 1 << LM;
+        constexpr int NG = TILE / R;
+        for (int g = tid; g < NG; g += THREADS) {
+            const int c = g & (C - 1), gi = g >> LOG2C;
+            const int blk = gi >> LM, n2 = gi & (M - 1);
+            const int base = (((blk << (LM + LR)) + n2) << LOG2C) + c;
+            float2 v[R];
+#pragma unroll
+            for (int i = 0; i < R; ++i) v[i] = T[base + ((i << LM) << LOG2C)];
+            dft<R, DIR>(v);
+            if constexpr (M > 1) {
+#pragma unroll
+                for (int k = 1; k < R; ++k) v[k] = ctw<DIR>(v[k], tw1[(n2 * k) << (4 * P)]);
+            }
+#pragma unroll
+            for (int i = 0; i < R; ++i) T[base + ((i << LM) << LOG2C)] = v[i];
+        }
+        __syncthreads();
+        col_fft<LOG2N1, DIR, P + 1>(T, tw1, tid);
+    }
+}
+
+// ---- A: int8 -> column FFTs -> x W_B^(n2 k1) -> Y[k1][n2] -------------------------------------------
+// grid (N1 tiles, rows); tile = columns [tile*C, (tile+1)*C).  Signal rows carry samples at n < L
+// (n1 < N1/2), the ref row at n >= L (src/crtlsdr.cc:205-207,215-218).
+template <int LOG2N1, bool IS_REF>
+__global__ __launch_bounds__(THREADS) void k_long_fwd_cols(const int8_t *__restrict__ rows, int row_begin, uint32_t xor80,
+                                                           LongTw tw, float2 *__restrict__ Y)
+{
+    constexpr int N1 = 1 << LOG2N1, LOG2C = LOG2N2 - LOG2N1, C = 1 << LOG2C, H = N1 / 2;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float2 *T = reinterpret_cast<float2 *>(smem);
+    const int tid = threadIdx.x, tile = blockIdx.x;
+    const size_t B = (size_t)N1 * N2;
+    const int row = IS_REF ? 0 : row_begin + (int)blockIdx.y;
+    const uint32_t *src = reinterpret_cast<const uint32_t *>(rows + (size_t)row * B); // word = 2 samples
+    // non-zero half: H tile rows of C samples; the other H rows are zero
+    for (int w = tid; w < H * C / 2; w += THREADS) {
+        const int n1 = (2 * w) >> LOG2C, c = (2 * w) & (C - 1);
+        const uint32_t u = src[((size_t)n1 * N2 + (size_t)tile * C + c) >> 1] ^ xor80;
+        const int r = IS_REF ? n1 + H : n1;
+        T[(r << LOG2C) + c] = make_float2(i8_to_f32(sext8(u, 0)), i8_to_f32(sext8(u, 1)));
+        T[(r << LOG2C) + c + 1] = make_float2(i8_to_f32(sext8(u, 2)), i8_to_f32(sext8(u, 3)));
+    }
+    for (int e = tid; e < H * C; e += THREADS) T[((IS_REF ? 0 : H) << LOG2C) + e] = make_float2(0.f, 0.f);
+    __syncthreads();
+    col_fft<LOG2N1, -1>(T, tw.tw1, tid);
+    float2 *Yr = Y + (size_t)(IS_REF ? 0 : blockIdx.y) * B;
+    for (int e = tid; e < TILE; e += THREADS) {
+        const int j = e >> LOG2C, c = e & (C - 1);
+        const int k1 = rev_n1<LOG2N1>(j), n2 = tile * C + c;
+        Yr[(size_t)k1 * N2 + n2] = cmul(T[e], tw_big(tw, (uint32_t)n2 * (uint32_t)k1));
+    }
+}
+
+// ---- B: 16384-point row transforms ----------------------------------------------------------------------
+// grid (N1 rows k1, signal rows).  IS_REF: forward only, conj -> refspec (DIF order).
+// signal: forward, x conj(ref spectrum), inverse, natural order back in place.
+template <bool IS_REF>
+__global__ __launch_bounds__(THREADS) void k_long_rows(float2 *__restrict__ Y, const LongTw tw, float2 *__restrict__ refspec)
+{
+    using G = FftGeom<LOG2N2>;
+    constexpr int NP = G::NPASS;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float2 *A = reinterpret_cast<float2 *>(smem);
+    const int tid = threadIdx.x;
+    const size_t N1 = gridDim.x;
+    float2 *line = Y + ((size_t)blockIdx.y * N1 + blockIdx.x) * N2;
+    float2 *rs = refspec + (size_t)blockIdx.x * N2;
+    for (int j = tid; j < N2; j += THREADS) A[j] = line[j];
+    __syncthreads();
+    if constexpr (IS_REF) {
+        fft_dif_range<LOG2N2, -1, 0, NP>(A, tw.tw2, tid);
+        for (int j = tid; j < N2; j += THREADS) rs[j] = make_float2(A[j].x, -A[j].y);
+    } else {
+        fft_dif_range<LOG2N2, -1, 0, NP - 1>(A, tw.tw2, tid);
+        constexpr int LR = G::log2r(NP - 1), R = 1 << LR, NG = N2 / R;
+        for (int g = tid; g < NG; g += THREADS) {
+            float2 v[R];
+#pragma unroll
+            for (int i = 0; i < R; ++i) v[i] = A[g * R + i];
+            dft<R, -1>(v);
+#pragma unroll
+            for (int i = 0; i < R; ++i) v[i] = cmul(v[i], rs[g * R + i]);
+            dft<R, +1>(v);
+#pragma unroll
+            for (int i = 0; i < R; ++i) A[g * R + i] = v[i];
+        }
+        __syncthreads();
+        fft_dit_range<LOG2N2, +1, 0, NP - 1>(A, tw.tw2, tid);
+        for (int j = tid; j < N2; j += THREADS) line[j] = A[j];
+    }
+}
+
+// ---- C: x conj W_B^(n2 k1) -> inverse column FFTs -> |.|^2 -> per-tile argmax ----------------------------
+struct LongPartial {
+    float m;
+    int idx;
+};
+
+template <int LOG2N1>
+__global__ __launch_bounds__(THREADS) void k_long_inv_cols(const float2 *__restrict__ Z, LongTw tw, LongPartial *__restrict__ part)
+{
+    constexpr int N1 = 1 << LOG2N1, LOG2C = LOG2N2 - LOG2N1, C = 1 << LOG2C;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float2 *T = reinterpret_cast<float2 *>(smem);
+    LongPartial *wred = reinterpret_cast<LongPartial *>(smem + sizeof(float2) * TILE);
+    const int tid = threadIdx.x, tile = blockIdx.x;
+    const size_t B = (size_t)N1 * N2;
+    const float2 *Zr = Z + (size_t)blockIdx.y * B;
+    for (int e = tid; e < TILE; e += THREADS) {
+        const int k1 = e >> LOG2C, c = e & (C - 1), n2 = tile * C + c;
+        T[e] = cmulc(Zr[(size_t)k1 * N2 + n2], tw_big(tw, (uint32_t)n2 * (uint32_t)k1));
+    }
+    __syncthreads();
+    col_fft<LOG2N1, +1>(T, tw.tw1, tid);
+    float bm = -1.0f;
+    int bi = 0x7fffffff;
+    for (int e = tid; e < TILE; e += THREADS) {
+        const int j = e >> LOG2C, c = e & (C - 1);
+        const int n = rev_n1<LOG2N1>(j) * N2 + tile * C + c; // natural sample index of this output
+        const float2 y = T[e];
+        const float m = fmaf(y.x, y.x, y.y * y.y);
+        if (m > bm || (m == bm && n < bi)) { bm = m; bi = n; }
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        const float om = __shfl_xor(bm, off, 64);
+        const int oi = __shfl_xor(bi, off, 64);
+        if (om > bm || (om == bm && oi < bi)) { bm = om; bi = oi; }
+    }
+    if ((tid & 63) == 0) wred[tid >> 6] = LongPartial{bm, bi};
+    __syncthreads();
+    if (tid == 0) {
+        LongPartial b = wred[0];
+        for (int w = 1; w < THREADS / 64; ++w)
+            if (wred[w].m > b.m || (wred[w].m == b.m && wred[w].idx < b.idx)) b = wred[w];
+        part[(size_t)blockIdx.y * N1 + tile] = b;
+    }
+}
+
+// ---- D: reduce the per-tile partials, parabolic neighbours, publish -----------------------------------
+// y[n] for a single n is an N1-term sum over the column of Z that holds it:
+//   y[n1 N2 + n2] = sum_k1 Z[k1][n2] conj(W_B^(n2 k1)) conj(W_N1^(n1 k1))
+__global__ __launch_bounds__(256) void k_long_finalize(const float2 *__restrict__ Z, const LongPartial *__restrict__ part, LongTw tw,
+                                                       int N1, XcorrArgs a)
+{
+    __shared__ LongPartial sp[256];
+    __shared__ float snb[2][2 * 256];
+    const int tid = threadIdx.x, row = a.row_begin + (int)blockIdx.x, t = 0;
+    if (xcorr_skip(a, row, t, tid)) return;
+    const size_t B = (size_t)N1 * N2;
+    LongPartial b = {-1.0f, 0x7fffffff};
+    for (int i = tid; i < N1; i += 256) {
+        const LongPartial p = part[(size_t)blockIdx.x * N1 + i];
+        if (p.m > b.m || (p.m == b.m && p.idx < b.idx)) b = p;
+    }
+    sp[tid] = b;
+    __syncthreads();
+    for (int s = 128; s >= 1; s >>= 1) {
+        if (tid < s) {
+            const LongPartial o = sp[tid + s];
+            if (o.m > sp[tid].m || (o.m == sp[tid].m && o.idx < sp[tid].idx)) sp[tid] = o;
+        }
+        __syncthreads();
+    }
+    const float gm = sp[0].m;
+    int gi = sp[0].idx;
+    if ((unsigned)gi >= (unsigned)B) gi = 0;
+    const float2 *Zr = Z + (size_t)blockIdx.x * B;
+#pragma unroll
+    for (int side = 0; side < 2; ++side) {
+        const long n = (long)gi + (side ? 1 : -1);
+        float2 acc = make_float2(0.f, 0.f);
+        if (n >= 0 && n < (long)B) {
+            const uint32_t n1 = (uint32_t)(n >> LOG2N2), n2 = (uint32_t)(n & (N2 - 1));
+            for (int k1 = tid; k1 < N1; k1 += 256) {
+                float2 z = cmulc(Zr[(size_t)k1 * N2 + n2], tw_big(tw, n2 * (uint32_t)k1));
+                z = cmulc(z, tw.tw1[(n1 * (uint32_t)k1) & (uint32_t)(N1 - 1)]);
+                acc = cadd(acc, z);
+            }
+        }
+        snb[side][2 * tid] = acc.x;
+        snb[side][2 * tid + 1] = acc.y;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        float mn[2];
+        for (int side = 0; side < 2; ++side) {
+            float sx = 0.f, sy = 0.f;
+            for (int i = 0; i < 256; ++i) { sx += snb[side][2 * i]; sy += snb[side][2 * i + 1]; }
+            mn[side] = fmaf(sx, sx, sy * sy);
+        }
+        float D = 0.0f;
+        if (gi > 0 && gi < (int)B - 1) {
+            const float den = (mn[0] - 2.0f * gm) + mn[1];
+            if (den != 0.0f) D = (0.5f * (mn[0] - mn[1])) / den;
+        }
+        const int L = (int)(B >> 1);
+        xcorr_publish(a, row, t, gi - L /* src/ccoherent.cc:232 */, sqrtf(gm / (float)L) /* :204 */, D);
+    }
+}
+
+} // namespace lb
+} // namespace crsdr

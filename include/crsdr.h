@@ -84,8 +84,9 @@ int crsdr_indexofmax(uint32_t *index, const float *in, int n);
 /* cdsp::fft(out,in,fft_scheme*)  include/cdsp.h:65, src/cdsp.cc:110-120, with the plan geometry
  * of src/ccoherent.cc:78-93 passed explicitly instead of an fftwf_plan: `howmany` contiguous
  * transforms of n complex points (dist n, stride 1), sign -1 = FFTW_FORWARD, +1 =
- * FFTW_BACKWARD, unnormalised, out of place.  n: power of two, 16 <= n <= 16384 (LDS-resident)
- * or 2^15 <= n <= 2^22 (multi-pass, HBM-streaming). */
+ * FFTW_BACKWARD, unnormalised, out of place.  n: power of two, 16 <= n <= 16384 (one
+ * LDS-resident transform per workgroup; longer transforms exist only inside the plan, where the
+ * four-step order never has to be undone). */
 int crsdr_fft(float *out, const float *in, int n, int sign, int howmany);
 
 /* ------------------------------------------------------------------------------------------
@@ -120,7 +121,9 @@ typedef struct crsdr_plan crsdr_plan;
 
 typedef struct crsdr_plan_desc {
     int32_t nrows;      /* N: reference row + signal rows in the receive matrix (hdr0::N) */
-    int32_t blocksize;  /* B: int8 values per row per block; power of two, 16..16384 */
+    int32_t blocksize;  /* B: int8 values per row per block; power of two, 16..4194304.  B <= 16384:
+                           one LDS-resident transform per row; B > 16384 (config 5: 2^21): four-step
+                           B = (B/16384) x 16384 transform streamed through HBM, max_batch = 1 */
     int32_t mode;       /* CRSDR_MODE_* */
     int32_t device;     /* HIP device ordinal */
     int32_t row_begin;  /* first signal row this plan owns (>= 1); 0 = default (1) */
