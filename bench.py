@@ -218,6 +218,22 @@ def main():
                                              "traffic": _committed_traffic("k_align_quant")},
                                 "hbm_read_frac": (nrows * B) * (n_l / dt_l) / (world * HBM_PEAK_GBS * 1e9)}
 
+    # ---- extra: host-buffer (PCIe-inclusive) rate -- reported for DESIGN.md, never `value` -----------
+    if not args.no_extras and world == 1:
+        hp = b.Plan(nrows, B, mode, device=local_rank, max_batch=T)
+        hrows = np.ascontiguousarray(np.broadcast_to(host_block0, (T, nrows, B)))
+        hp.submit(hrows, seq=0)
+        hp.fetch()
+        t0 = time.perf_counter()
+        nh = 3
+        for i in range(nh):
+            hp.submit(hrows, seq=i * T)
+            hp.fetch()                      # D2H of the last packet; one packet per batch is copied back
+        dth = time.perf_counter() - t0
+        result["pcie_inclusive"] = {"blocks_per_s": nh * T / dth, "note": f"pageable host int8 in ({T} blocks per submit), "
+                                    "host packet of the last block out; PCIe Gen5 x16"}
+        hp.close()
+
     # ---- CPU baseline: the oracle (C port of the reference path) on this host's cores --------------
     if rank == 0 and not args.no_cpu_baseline and world == 1:
         result["cpu_baseline"] = _cpu_baseline(args, host_block0, nrows, B, mode)
