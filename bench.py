@@ -70,11 +70,19 @@ def main():
         raise SystemExit("N > 1 must be launched with torch.distributed.run (one rank per GPU)")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    # CRSDR_BENCH_REHEARSAL=1: every rank on cuda:0, gloo transport with the slabs staged through host
+    # memory -- exercises the sharded plans / exchange bookkeeping on a one-GPU box (numbers meaningless)
+    rehearsal = os.environ.get("CRSDR_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if rehearsal:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     nsig, L = args.nsig, args.L
     nrows, B = nsig + 1, 2 * L
@@ -96,31 +104,37 @@ def main():
     plan = b.Plan(nrows, B, mode, device=local_rank, row_begin=slab.row_begin, row_count=slab.row_count, max_batch=T)
     stream = torch.cuda.current_stream()
     plan.set_stream(stream.cuda_stream)
-    # two sets of T packets (double-buffered against the gather); matrix of every packet 16-byte aligned
+    # NSETS sets of T packets (ring-buffered against the exchange in flight); matrix of every packet 16-byte aligned
+    NSETS = 4 if world > 1 else 2
     pstride = (plan.packet_bytes + 255) // 256 * 256
-    packets = [torch.zeros(pstride * T + 64, dtype=torch.uint8, device=dev) for _ in range(2)]
+    packets = [torch.zeros(pstride * T + 64, dtype=torch.uint8, device=dev) for _ in range(NSETS)]
     pk_off = [(-(p.data_ptr() + plan.matrix_offset)) % 16 for p in packets]
     pk_view = [[p[o + t * pstride: o + t * pstride + plan.packet_bytes] for t in range(T)] for p, o in zip(packets, pk_off)]
     flags = b.REFNOISE_ENABLED | b.INPUT_READY
-    works = [[], []]
+    works = [[] for _ in range(NSETS)]
 
     def run_batch(ib, nb, fl=flags):
-        """blocks [ib*T, ib*T + nb) of the stream: one submit, then one gather per block"""
-        k = ib & 1
+        """blocks [ib*T, ib*T + nb) of the stream: one submit, then ONE grouped exchange for the batch
+        (block b is assembled on rank b mod G: every link carries one slab per block, no hot root)"""
+        k = ib % NSETS
         for w in works[k]:
-            w.wait()                 # stream-level: the gathers that read this packet set are done
+            w.wait()                 # stream-level: the exchange that read this packet set is done
         works[k] = []
         plan.bind_packet(pk_view[k][0].data_ptr(), pstride)
         first_buf = (ib * T) % nbuf
         plan.submit(d_in[first_buf].data_ptr(), seq=ib * T, flags=fl, nblocks=nb, block_stride=block_bytes)
-        if world > 1:
-            for t in range(nb):
-                w = sharding.gather_matrix(pk_view[k][t], nrows, B, slab, sharding.gather_root(ib * T + t, world), async_op=True)
-                if w is not None:
-                    works[k].append(w)
+        if world > 1 and not rehearsal:
+            works[k] = list(sharding.gather_batch(pk_view[k][:nb], nrows, B, slab, ib * T))
+        elif world > 1:
+            plan.sync()
+            host = [v.cpu() for v in pk_view[k][:nb]]
+            for w in sharding.gather_batch(host, nrows, B, slab, ib * T):
+                w.wait()
+            for v, h in zip(pk_view[k][:nb], host):
+                v.copy_(h)
 
     def fence():
-        for k in (0, 1):
+        for k in range(NSETS):
             for w in works[k]:
                 w.wait()
             works[k] = []
@@ -144,7 +158,7 @@ def main():
         fence()
         dt = time.perf_counter() - t0
         if world > 1:
-            t = torch.tensor([dt], device=dev, dtype=torch.float64)
+            t = torch.tensor([dt], device="cpu" if rehearsal else dev, dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
         return dt
@@ -166,6 +180,23 @@ def main():
     own = slice(slab.row_begin, slab.row_begin + slab.row_count)
     lags_ok = bool(np.array_equal(out["lag"][own], params.d[slab.row_begin - 1: slab.row_begin - 1 + slab.row_count]))
 
+    # the last batch's packets: on the rank that roots a block every slab must have arrived (row 0 of
+    # every other rank's slab is non-zero int8 data with overwhelming probability)
+    assembled_ok = True
+    if world > 1:
+        torch.cuda.synchronize()
+        nfull = args.steps // T
+        if nfull:
+            ib = nfull - 1
+            for t_ in range(T):
+                if sharding.gather_root(ib * T + t_, world) == rank:
+                    m = sharding.matrix_view(pk_view[ib % NSETS][t_], nrows, B)
+                    for r in range(world):
+                        assembled_ok &= bool(m[1 + r * slab.rows_per_rank].ne(0).any().item())
+        flag = torch.tensor([1 if assembled_ok else 0], device="cpu" if rehearsal else dev, dtype=torch.int32)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        assembled_ok = bool(flag.item())
+
     result = None
     if rank == 0:
         A_block = nrows * B                                   # algorithmic bytes per block
@@ -183,7 +214,7 @@ def main():
                                    f"(FFT xcorr every block), {args.mode} mode, inputs resident in HBM, "
                                    f"{nbuf} rotating input blocks, {T} blocks per submit",
                        "rows": nrows, "L": L, "fft_len": B, "mode": args.mode, "batch": T,
-                       "parallelism": f"rows sharded x{world}, ref replicated, rotating-root int8 gather" if world > 1 else "single GPU"},
+                       "parallelism": f"rows sharded x{world}, ref replicated, rotating-root int8 gather (one grouped RCCL exchange per batch)" if world > 1 else "single GPU"},
             "roofline": {"bound": "hbm", "kernel": "k_xcorr_lag", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": _committed_traffic("k_xcorr_lag"),
                          "algorithmic_bytes_per_launch": k1_bytes, "avg_launch_ms": k1,
@@ -194,7 +225,7 @@ def main():
             "whole_path": {"algorithmic_bytes_per_block": A_block,
                            "hbm_read_frac": A_block * blocks_per_s / (world * HBM_PEAK_GBS * 1e9)},
             "kernel_ms": {k: (float(np.mean(v)) if len(v) else None) for k, v in k_ms.items()},
-            "lags_exact": lags_ok,
+            "lags_exact": lags_ok, "matrix_assembled": assembled_ok if world > 1 else None,
         }
 
     # ---- extras: locked steady state (phase path only) ---------------------------------------------

@@ -66,6 +66,37 @@ def gather_matrix(packet, nrows: int, B: int, slab: Slab, root: int, group=None,
     return dist.gather(mine, gather_list=None, dst=root, group=group, async_op=async_op)
 
 
+def gather_batch(packets, nrows: int, B: int, slab: Slab, first_block: int, group=None):
+    """Reassemble a whole batch with ONE grouped point-to-point exchange.
+
+    packets: list of T full-size packet tensors (block first_block + t each); this rank's plan
+    has written its slab (and the replicated row 0 + header) into every one of them.  Block b is
+    assembled on rank b mod G, so with T a multiple of G every GPU roots T/G blocks of the batch
+    and every xGMI link carries the same 2L x rows_per_rank bytes in each direction -- there is no
+    hot root, and the whole batch costs one RCCL group launch (ncclGroupStart/End under
+    torch.distributed.batch_isend_irecv) instead of T gathers.
+    Returns the list of work handles (empty for a single rank).
+    """
+    import torch.distributed as dist
+
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    if world == 1:
+        return []
+    per = slab.rows_per_rank
+    ops = []
+    for t, pk in enumerate(packets):
+        m = matrix_view(pk, nrows, B)
+        root = gather_root(first_block + t, world)
+        if rank == root:
+            for r in range(world):
+                if r != rank:
+                    ops.append(dist.P2POp(dist.irecv, m[1 + r * per: 1 + (r + 1) * per], r, group))
+        else:
+            ops.append(dist.P2POp(dist.isend, m[slab.row_begin: slab.row_begin + slab.row_count], root, group))
+    return dist.batch_isend_irecv(ops) if ops else []
+
+
 def gather_scalars(local, slab: Slab, root: int, group=None):
     """Gather per-row scalars (a [nrows, k] tensor holding this rank's rows) onto root in place."""
     import torch.distributed as dist

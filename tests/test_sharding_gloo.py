@@ -64,6 +64,54 @@ def _worker(rank, world, port, nsig, L, nblocks, outdir):
     dist.destroy_process_group()
 
 
+def _worker_batch(rank, world, port, nsig, L, T, outdir):
+    for p in (ROOT, os.path.join(ROOT, "oracle")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sharding = importlib.import_module("coherent-rtlsdr_amd.sharding")
+    synth = importlib.import_module("coherent-rtlsdr_amd.synth")
+    import oracle_py as O
+
+    nrows, B = nsig + 1, 2 * L
+    slab = sharding.slab_for_rank(nrows, world, rank)
+    params = synth.RowParams(nsig, L, 56, dmax=L // 8)
+    eng = O.Engine(nrows, B, O.DIGITAL)
+    mask = np.zeros(nrows, dtype=np.uint8)
+    mask[slab.row_begin: slab.row_begin + slab.row_count] = 1
+    own = np.zeros(nrows, dtype=bool)
+    own[0] = True
+    own[slab.row_begin: slab.row_begin + slab.row_count] = True
+    first = 3                                     # batch starts at block 3: roots 3 % G, 4 % G, ...
+    packets = []
+    for t in range(T):
+        rows, _ = synth.make_block(nsig, L, 56, first + t, params=params)
+        pkt = torch.from_numpy(eng.block(rows, seq=first + t, lag_mask=mask)["packet"].copy())
+        sharding.matrix_view(pkt, nrows, B)[torch.from_numpy(~own)] = 77   # poison what this rank does not own
+        packets.append(pkt)
+    for w in sharding.gather_batch(packets, nrows, B, slab, first):
+        w.wait()
+    for t in range(T):
+        if rank == sharding.gather_root(first + t, world):
+            np.save(os.path.join(outdir, f"bpkt_{t}.npy"), packets[t].numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_batched_rotating_root_exchange(world, tmp_path, oracle, synth):
+    # one grouped point-to-point exchange per batch, block b assembled on rank b mod G
+    nsig, L, T = 8, 256, 6
+    mp.spawn(_worker_batch, args=(world, _free_port(), nsig, L, T, str(tmp_path)), nprocs=world, join=True)
+    params = synth.RowParams(nsig, L, 56, dmax=L // 8)
+    eng = oracle.Engine(nsig + 1, 2 * L, oracle.DIGITAL)    # fresh engine from block 3, like the workers' engines
+    for t in range(T):
+        rows, _ = synth.make_block(nsig, L, 56, 3 + t, params=params)
+        exp = eng.block(rows, seq=3 + t)
+        assert np.array_equal(np.load(tmp_path / f"bpkt_{t}.npy"), exp["packet"]), t
+
+
 @pytest.mark.parametrize("world", [2, 4])
 def test_rotating_root_gather_reassembles_the_packet(world, tmp_path, oracle, synth):
     nsig, L, nblocks = 8, 256, 5
