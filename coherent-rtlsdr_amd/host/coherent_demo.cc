@@ -8,6 +8,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <unistd.h>
 
 #include "ccoherent.h"
 
@@ -46,8 +47,9 @@ static int cdsp_selftest()
 int main(int argc, char **argv)
 {
     int nsig = 3, L = 8192, blocks = 12, mode = CRSDR_MODE_DIGITAL, dmax = -1;
-    std::string dump;
+    std::string dump, zmqaddr;
     bool run_cdsp = false;
+    int pace_ms = 0;
     for (int i = 1; i < argc; ++i) {
         std::string a = argv[i];
         auto val = [&](int &v) { if (i + 1 < argc) v = std::atoi(argv[++i]); };
@@ -58,6 +60,9 @@ int main(int argc, char **argv)
         else if (a == "--faithful") mode = CRSDR_MODE_FAITHFUL;
         else if (a == "--dump" && i + 1 < argc) dump = argv[++i];
         else if (a == "--cdsp") run_cdsp = true;
+        else if (a == "--zmq" && i + 1 < argc) zmqaddr = argv[++i];           // e.g. tcp://127.0.0.1:5555 (reference: tcp://*:5555)
+        else if (a == "--zmq-debug" && i + 1 < argc) cpacketize::debugaddress = argv[++i];
+        else if (a == "--pace-ms") val(pace_ms);
     }
     int fails = 0;
     if (run_cdsp) fails += cdsp_selftest();
@@ -69,7 +74,8 @@ int main(int argc, char **argv)
     std::vector<std::unique_ptr<csyntheticsdr>> own;
     for (int k = 0; k < nsig; ++k) { own.emplace_back(new csyntheticsdr(&source, 1 + k, B)); devs.push_back(own.back().get()); }
     crefnoise refnoise;
-    cpacketize::init("tcp://*:5555", false, 1 + nsig, B);
+    cpacketize::init(zmqaddr, false, 1 + nsig, B);             // src/main.cc:261 binds tcp://*:5555
+    if (!zmqaddr.empty()) { std::printf("zmq publish on %s: %s\n", zmqaddr.c_str(), cpacketize::publishing() ? "bound" : "unavailable"); usleep(300 * 1000); }
     size_t packets = 0, last_bytes = 0; uint32_t last_seq = 0, last_N = 0, last_L = 0;
     cpacketize::sink = [&](const int8_t *p, size_t bytes, const std::complex<float> *, size_t) {
         const hdr0 *h = reinterpret_cast<const hdr0 *>(p);
@@ -86,6 +92,7 @@ int main(int argc, char **argv)
         for (auto *d : devs) d->requestfft();                 // "track" cadence: every row asks for a lag every block
         if (!coherent.step()) { std::fprintf(stderr, "step failed\n"); return 2; }
         cpacketize::send();                                    // main-thread publish loop, src/main.cc:277-279
+        if (pace_ms) usleep(pace_ms * 1000);
     }
     const csynth_params *p = source.get_params();
     for (int k = 0; k < nsig; ++k) {

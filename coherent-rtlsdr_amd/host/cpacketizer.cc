@@ -1,7 +1,41 @@
 // cpacketizer.cc -- see cpacketizer.h.  Layout and hand-off follow src/cpacketizer.cc:91-185.
 #include "cpacketizer.h"
 #include "cdsp.h"
+#include <cstdio>
 #include <cstring>
+#include <dlfcn.h>
+
+// ---- libzmq C API, resolved at run time (zmq.h: ZMQ_PUB = 1, ZMQ_LINGER = 17) ---------------------
+namespace {
+struct zmq_api {
+    void *lib = nullptr;
+    void *(*ctx_new)() = nullptr;
+    int (*ctx_term)(void *) = nullptr;
+    void *(*socket)(void *, int) = nullptr;
+    int (*close)(void *) = nullptr;
+    int (*bind)(void *, const char *) = nullptr;
+    int (*send)(void *, const void *, size_t, int) = nullptr;
+    int (*setsockopt)(void *, int, const void *, size_t) = nullptr;
+    bool load()
+    {
+        if (lib) return true;
+        const char *names[] = {"libzmq.so.5", "libzmq.so", "/opt/conda/lib/libzmq.so.5", "/usr/lib/x86_64-linux-gnu/libzmq.so.5"};
+        for (const char *n : names) { lib = dlopen(n, RTLD_NOW | RTLD_LOCAL); if (lib) break; }
+        if (!lib) return false;
+        ctx_new = (void *(*)())dlsym(lib, "zmq_ctx_new");
+        ctx_term = (int (*)(void *))dlsym(lib, "zmq_ctx_term");
+        socket = (void *(*)(void *, int))dlsym(lib, "zmq_socket");
+        close = (int (*)(void *))dlsym(lib, "zmq_close");
+        bind = (int (*)(void *, const char *))dlsym(lib, "zmq_bind");
+        send = (int (*)(void *, const void *, size_t, int))dlsym(lib, "zmq_send");
+        setsockopt = (int (*)(void *, int, const void *, size_t))dlsym(lib, "zmq_setsockopt");
+        return ctx_new && ctx_term && socket && close && bind && send && setsockopt;
+    }
+} zq;
+void *g_ctx = nullptr, *g_sock = nullptr, *g_dbg = nullptr;
+} // namespace
+std::string cpacketize::debugaddress = "tcp://*:5557";
+bool cpacketize::publishing() { return g_sock != nullptr; }
 
 int cpacketize::objcount = 0;
 uint32_t cpacketize::globalseqn = 0;
@@ -34,7 +68,7 @@ void cpacketize::resize_buffers(uint32_t N, uint32_t L)
     pcorrection.assign(N, std::complex<float>(0.0f, 0.0f));
 }
 
-void cpacketize::init(std::string /*address*/, bool noheader_, uint32_t nchannels_, uint32_t blocksize_)
+void cpacketize::init(std::string address, bool noheader_, uint32_t nchannels_, uint32_t blocksize_)
 {
     noheader = noheader_;                                      // src/cpacketizer.cc:58-74
     blocksize = blocksize_;
@@ -42,9 +76,32 @@ void cpacketize::init(std::string /*address*/, bool noheader_, uint32_t nchannel
     bufferfilled = false;
     globalseqn = 0;
     resize_buffers(nchannels_, blocksize_);
+    if (!address.empty()) {
+        if (!zq.load()) {
+            std::fprintf(stderr, "cpacketize: libzmq not found, packets go to the sink callback only\n");
+        } else {
+            const int linger = 0;
+            g_ctx = zq.ctx_new();                              // context = new zmq::context_t(1)
+            g_sock = zq.socket(g_ctx, 1 /* ZMQ_PUB */);        // socket->bind(address)
+            zq.setsockopt(g_sock, 17 /* ZMQ_LINGER */, &linger, sizeof(linger));
+            if (zq.bind(g_sock, address.c_str()) != 0) {
+                std::fprintf(stderr, "cpacketize: cannot bind %s\n", address.c_str());
+                zq.close(g_sock); g_sock = nullptr;
+            }
+            g_dbg = zq.socket(g_ctx, 1);                       // debugsocket->bind("tcp://*:5557")
+            zq.setsockopt(g_dbg, 17, &linger, sizeof(linger));
+            if (zq.bind(g_dbg, debugaddress.c_str()) != 0) { zq.close(g_dbg); g_dbg = nullptr; }
+        }
+    }
 }
 
-void cpacketize::cleanup() { packetbuf0.reset(); packetbuf1.reset(); packetlen = 0; }
+void cpacketize::cleanup()
+{
+    if (g_sock) { zq.close(g_sock); g_sock = nullptr; }        // src/cpacketizer.cc:76-83
+    if (g_dbg) { zq.close(g_dbg); g_dbg = nullptr; }
+    if (g_ctx) { zq.ctx_term(g_ctx); g_ctx = nullptr; }
+    packetbuf0.reset(); packetbuf1.reset(); packetlen = 0;
+}
 void cpacketize::request_exit() { { std::lock_guard<std::mutex> l(bmutex); do_exit = true; } cv.notify_all(); }
 
 int cpacketize::send()
@@ -65,6 +122,8 @@ int cpacketize::send()
         hdr->L = blocksize >> 1;
         hdr->unused = 0;
     }
+    if (g_sock) zq.send(g_sock, packetbuf1.get(), packetlen, 0);                                         // :125
+    if (g_dbg) zq.send(g_dbg, pcorrection.data(), (size_t)objcount * sizeof(std::complex<float>), 0);      // :127
     if (sink) sink(packetbuf1.get(), packetlen, pcorrection.data(), (size_t)objcount);
     return 0;
 }

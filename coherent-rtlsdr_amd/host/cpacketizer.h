@@ -1,7 +1,8 @@
 // cpacketizer.h -- the write side of the reference's cpacketize (include/cpacketizer.h:32-79,
 // src/cpacketizer.cc:91-185): static double-buffered packet  hdr0 + u32 readcnt[N] + int8 IQ[N][L][2].
-// The ZMQ PUB sockets of init()/send() (ports 5555 / 5557) are outside the hot path:
-// send() hands the finished packet and the N phase factors to a sink callback instead.
+// init()/send() publish like the reference (ZMQ PUB on `address`, phase factors on the debug PUB,
+// src/cpacketizer.cc:58-74,109-129) through libzmq's C API, loaded at run time (cppzmq's zmq.hpp is
+// not available here); without libzmq, or with an empty address, packets only reach the sink callback.
 #ifndef PACKETIZEH
 #define PACKETIZEH
 #include <complex>
@@ -36,6 +37,8 @@ class cpacketize {
 public:
     typedef std::function<void(const int8_t *packet, size_t bytes, const std::complex<float> *phase, size_t n)> sink_t;
     static sink_t sink;
+    static std::string debugaddress;   // reference: "tcp://*:5557" (src/cpacketizer.cc:66); set before init()
+    static bool publishing();          // true when the ZMQ PUB sockets are bound
     // packet bytes for N channels of blocksize L: (16 + 4N) + N*L.  The reference allocates and
     // sends 2*N*L data bytes (src/cpacketizer.cc:95), of which clients read N*L
     // (matlabclient/zmqsdr.c:121-143); the tail padding is not reproduced.
