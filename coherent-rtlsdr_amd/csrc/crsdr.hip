@@ -200,13 +200,14 @@ static hipError_t launch_long_fwd_cols(hipStream_t s, int nrows_launch, const in
     hipLaunchKernelGGL(kern, dim3(1 << LOG2N1, nrows_launch), dim3(lb::THREADS), lb::LDS_BYTES, s, rows, row_begin, xor80, tw, Y);
     return hipGetLastError();
 }
+// stage B: the 16384-point row transforms run on the 32x32x16 structure of xcorr14.hpp
 template <bool IS_REF>
-static hipError_t launch_long_rows(hipStream_t s, int n1, int nrows_launch, float2 *Y, const lb::LongTw &tw, float2 *refspec)
+static hipError_t launch_long_rows(hipStream_t s, int n1, int nrows_launch, float2 *Y, const float2 *twA, const float2 *twB, float2 *refspec)
 {
-    auto kern = lb::k_long_rows<IS_REF>;
-    hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lb::LDS_BYTES);
+    auto kern = x14::k_rows14_cf32<IS_REF>;
+    hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, x14::LDS_BYTES);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(kern, dim3(n1, nrows_launch), dim3(lb::THREADS), lb::LDS_BYTES, s, Y, tw, refspec);
+    hipLaunchKernelGGL(kern, dim3(n1, nrows_launch), dim3(x14::THREADS), x14::LDS_BYTES, s, Y, twA, twB, (float4 *)refspec);
     return hipGetLastError();
 }
 template <int LOG2N1>
@@ -478,7 +479,7 @@ static int plan_alloc(crsdr_plan *p)
     HIP_TRY(hipEventCreate(&p->ev_start));
     HIP_TRY(hipEventCreate(&p->ev_stop));
     { int rc = make_twiddles(p->longblock ? lb::N2 : p->B, &p->d_tw); if (rc) return rc; }
-    if (p->log2n == 14) { int rc = make_twiddles14(&p->d_twA, &p->d_twB); if (rc) return rc; }
+    if (p->log2n == 14 || p->longblock) { int rc = make_twiddles14(&p->d_twA, &p->d_twB); if (rc) return rc; }
     if (p->longblock) {
         const size_t Bz = (size_t)p->B, n1 = Bz >> lb::LOG2N2;
         int rc;
@@ -713,7 +714,7 @@ extern "C" int crsdr_plan_submit_batch(crsdr_plan *p, const void *rows, int mem_
         hipEvent_t *pe0 = prof_pair(p, CRSDR_KERNEL_REF_SPECTRUM);
         if (pe0) HIP_TRY(hipEventRecord(pe0[0], S));
         HIP_TRY(CRSDR_DISPATCH_N1(l1, (launch_long_fwd_cols<LG, true>(S, 1, d_in, 0, xor80, tw, p->d_Yref))));
-        HIP_TRY(launch_long_rows<true>(S, n1, 1, p->d_Yref, tw, p->d_refspec[0]));
+        HIP_TRY(launch_long_rows<true>(S, n1, 1, p->d_Yref, p->d_twA, p->d_twB, p->d_refspec[0]));
         if (pe0) HIP_TRY(hipEventRecord(pe0[1], S));
         XcorrArgs xa;
         xa.rows = d_in; xa.block_stride = d_stride; xa.refspec = p->d_refspec[0]; xa.lag_mask = d_mask;
@@ -723,7 +724,7 @@ extern "C" int crsdr_plan_submit_batch(crsdr_plan *p, const void *rows, int mem_
         hipEvent_t *pe1 = prof_pair(p, CRSDR_KERNEL_XCORR_LAG);
         if (pe1) HIP_TRY(hipEventRecord(pe1[0], S));
         HIP_TRY(CRSDR_DISPATCH_N1(l1, (launch_long_fwd_cols<LG, false>(S, p->row_count, d_in, p->row_begin, xor80, tw, p->d_Y))));
-        HIP_TRY(launch_long_rows<false>(S, n1, p->row_count, p->d_Y, tw, p->d_refspec[0]));
+        HIP_TRY(launch_long_rows<false>(S, n1, p->row_count, p->d_Y, p->d_twA, p->d_twB, p->d_refspec[0]));
         HIP_TRY(CRSDR_DISPATCH_N1(l1, (launch_long_inv_cols<LG>(S, p->row_count, p->d_Y, tw, p->d_part))));
         hipLaunchKernelGGL(lb::k_long_finalize, dim3(p->row_count), dim3(256), 0, S, p->d_Y, p->d_part, tw, n1, xa);
         HIP_TRY(hipGetLastError());

@@ -5,7 +5,7 @@
 // split  B = N1 x N2,  N2 = 16384 (the LDS-resident size),  N1 = B / 16384 in {2..256}:
 //
 //   x[n1 N2 + n2] --A: N1-point column FFTs, x W_B^(n2 k1)--> Y[k1][n2]
-//                 --B: 16384-point row FFTs (x conj(ref), inverse)--> Z[k1][n2]
+//                 --B: 16384-point row FFTs (x conj(ref), inverse), xcorr14.hpp--> Z[k1][n2]
 //                 --C: x conj W_B^(n2 k1), inverse N1-point column FFTs, |.|^2, argmax--> partials
 //                 --D: reduce partials, parabolic neighbours from N1-term sums--> lag, mag, frac
 //
@@ -109,44 +109,7 @@ __global__ __launch_bounds__(THREADS) void k_long_fwd_cols(const int8_t *__restr
     }
 }
 
-// ---- B: 16384-point row transforms ----------------------------------------------------------------------
-// grid (N1 rows k1, signal rows).  IS_REF: forward only, conj -> refspec (DIF order).
-// signal: forward, x conj(ref spectrum), inverse, natural order back in place.
-template <bool IS_REF>
-__global__ __launch_bounds__(THREADS) void k_long_rows(float2 *__restrict__ Y, const LongTw tw, float2 *__restrict__ refspec)
-{
-    using G = FftGeom<LOG2N2>;
-    constexpr int NP = G::NPASS;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    float2 *A = reinterpret_cast<float2 *>(smem);
-    const int tid = threadIdx.x;
-    const size_t N1 = gridDim.x;
-    float2 *line = Y + ((size_t)blockIdx.y * N1 + blockIdx.x) * N2;
-    float2 *rs = refspec + (size_t)blockIdx.x * N2;
-    for (int j = tid; j < N2; j += THREADS) A[j] = line[j];
-    __syncthreads();
-    if constexpr (IS_REF) {
-        fft_dif_range<LOG2N2, -1, 0, NP>(A, tw.tw2, tid);
-        for (int j = tid; j < N2; j += THREADS) rs[j] = make_float2(A[j].x, -A[j].y);
-    } else {
-        fft_dif_range<LOG2N2, -1, 0, NP - 1>(A, tw.tw2, tid);
-        constexpr int LR = G::log2r(NP - 1), R = 1 << LR, NG = N2 / R;
-        for (int g = tid; g < NG; g += THREADS) {
-            float2 v[R];
-#pragma unroll
-            for (int i = 0; i < R; ++i) v[i] = A[g * R + i];
-            dft<R, -1>(v);
-#pragma unroll
-            for (int i = 0; i < R; ++i) v[i] = cmul(v[i], rs[g * R + i]);
-            dft<R, +1>(v);
-#pragma unroll
-            for (int i = 0; i < R; ++i) A[g * R + i] = v[i];
-        }
-        __syncthreads();
-        fft_dit_range<LOG2N2, +1, 0, NP - 1>(A, tw.tw2, tid);
-        for (int j = tid; j < N2; j += THREADS) line[j] = A[j];
-    }
-}
+// ---- B: 16384-point row transforms: x14::k_rows14_cf32 (xcorr14.hpp), the K1 structure on cf32 lines ---------
 
 // ---- C: x conj W_B^(n2 k1) -> inverse column FFTs -> |.|^2 -> per-tile argmax ----------------------------
 struct LongPartial {
