@@ -96,7 +96,7 @@ def lib():
     L.crsdr_plan_packet_stride.argtypes = [vp]
     L.crsdr_plan_packet_stride.restype = C.c_size_t
     L.crsdr_plan_last_elapsed_ms.argtypes = [vp, C.POINTER(C.c_float)]
-    L.crsdr_plan_enable_profiling.argtypes = [vp, C.c_int]
+    L.crsdr_plan_enable_profiling.argtypes = [vp, C.c_int, C.c_uint32]
     L.crsdr_plan_kernel_times.argtypes = [vp, C.c_int, f32p, C.c_int, C.POINTER(C.c_int)]
     _lib = L
     return L
@@ -271,8 +271,9 @@ class Plan:
         _check(lib().crsdr_plan_last_elapsed_ms(self._h, C.byref(ms)))
         return float(ms.value)
 
-    def enable_profiling(self, slots: int):
-        _check(lib().crsdr_plan_enable_profiling(self._h, int(slots)))
+    def enable_profiling(self, slots: int, kernel_mask: int = 0xF):
+        """kernel_mask: bit KERNEL_*; 1 << 31 adds whole-submit start/stop events"""
+        _check(lib().crsdr_plan_enable_profiling(self._h, int(slots), int(kernel_mask)))
 
     def kernel_times_ms(self, which: int, capacity: int = 4096) -> np.ndarray:
         out = np.zeros(capacity, dtype=np.float32)

@@ -433,6 +433,7 @@ struct crsdr_plan {
     bool submitted = false;
     // optional per-kernel event pairs (crsdr_plan_enable_profiling)
     int prof_slots = 0;
+    uint32_t prof_mask = 0;              // bit k: kernel k gets an event pair; bit 31: whole-submit start/stop
     long prof_count = 0;                 // submits recorded since enable
     std::vector<hipEvent_t> prof_ev;     // [slot][kernel][begin,end]
     std::vector<unsigned char> prof_has; // [slot][kernel]
@@ -442,7 +443,7 @@ constexpr int kProfKernels = 4;
 
 static hipEvent_t *prof_pair(crsdr_plan *p, int which)
 {
-    if (!p->prof_slots) return nullptr;
+    if (!p->prof_slots || !(p->prof_mask & (1u << which))) return nullptr;
     const int slot = (int)(p->prof_count % p->prof_slots);
     p->prof_has[(size_t)slot * kProfKernels + which] = 1;
     return &p->prof_ev[((size_t)slot * kProfKernels + which) * 2];
@@ -694,7 +695,7 @@ extern "C" int crsdr_plan_submit_batch(crsdr_plan *p, const void *rows, int mem_
     if (p->prof_slots) {
         const int ps = (int)(p->prof_count % p->prof_slots);
         for (int k = 0; k < kProfKernels; ++k) p->prof_has[(size_t)ps * kProfKernels + k] = 0;
-        HIP_TRY(hipEventRecord(p->ev_start, S));
+        if (p->prof_mask & (1u << 31)) HIP_TRY(hipEventRecord(p->ev_start, S));
     }
 
     const int pin = p->phase_cur, pout = pin ^ 1;
@@ -784,7 +785,7 @@ extern "C" int crsdr_plan_submit_batch(crsdr_plan *p, const void *rows, int mem_
     }
     p->phase_cur = pout;
     p->last_nblocks = nblocks;
-    if (p->prof_slots) { HIP_TRY(hipEventRecord(p->ev_stop, S)); p->prof_count++; }
+    if (p->prof_slots) { if (p->prof_mask & (1u << 31)) HIP_TRY(hipEventRecord(p->ev_stop, S)); p->prof_count++; }
     p->submitted = true;
     return CRSDR_OK;
 }
@@ -821,21 +822,22 @@ extern "C" int crsdr_plan_fetch(crsdr_plan *p, int32_t *lag, float *mag, float *
 extern "C" int crsdr_plan_last_elapsed_ms(crsdr_plan *p, float *ms)
 {
     if (!p || !ms) return fail(CRSDR_EINVAL, "plan_last_elapsed_ms: NULL argument");
-    if (!p->submitted || !p->prof_slots) return fail(CRSDR_ESTATE, "plan_last_elapsed_ms: enable profiling and submit first");
+    if (!p->submitted || !p->prof_slots || !(p->prof_mask & (1u << 31)))
+        return fail(CRSDR_ESTATE, "plan_last_elapsed_ms: enable profiling with CRSDR_PROFILE_SUBMIT and submit first");
     HIP_TRY(hipSetDevice(p->device));
     HIP_TRY(hipEventSynchronize(p->ev_stop));
     HIP_TRY(hipEventElapsedTime(ms, p->ev_start, p->ev_stop));
     return CRSDR_OK;
 }
 
-extern "C" int crsdr_plan_enable_profiling(crsdr_plan *p, int slots)
+extern "C" int crsdr_plan_enable_profiling(crsdr_plan *p, int slots, uint32_t kernel_mask)
 {
     if (!p || slots < 0 || slots > 4096) return fail(CRSDR_EINVAL, "plan_enable_profiling: bad argument");
     int rc = crsdr_plan_sync(p);
     if (rc) return rc;
     for (hipEvent_t e : p->prof_ev) if (e) (void)hipEventDestroy(e);
     p->prof_ev.clear(); p->prof_has.clear();
-    p->prof_slots = 0; p->prof_count = 0;
+    p->prof_slots = 0; p->prof_count = 0; p->prof_mask = kernel_mask;
     if (slots == 0) return CRSDR_OK;
     p->prof_ev.assign((size_t)slots * kProfKernels * 2, nullptr);
     p->prof_has.assign((size_t)slots * kProfKernels, 0);

@@ -207,15 +207,20 @@ int crsdr_plan_device_buffers(crsdr_plan *plan, void **packet, void **lag, void 
  * against a gather in flight is the caller's business. */
 int crsdr_plan_bind_packet(crsdr_plan *plan, void *device_packet, size_t packet_stride);
 
-/* With profiling enabled: elapsed GPU milliseconds on the plan's stream between the start and
- * the end of the most recent submit. */
+/* With profiling enabled (CRSDR_PROFILE_SUBMIT): elapsed GPU milliseconds on the plan's stream
+ * between the start and the end of the most recent submit. */
 int crsdr_plan_last_elapsed_ms(crsdr_plan *plan, float *ms);
 
 /* Per-kernel timing with hipEvents recorded on the stream each kernel is launched on.
- * enable: keep event pairs for the last `slots` submits (0 disables).  kernel_times: copy the
- * durations (ms) of kernel `which` for the submits recorded since enable, oldest first. */
+ * enable: keep event pairs for the last `slots` submits (0 disables) for the kernels in
+ * `kernel_mask` (bit CRSDR_KERNEL_*; CRSDR_PROFILE_SUBMIT adds whole-submit start/stop events --
+ * every recorded pair costs a few microseconds of stream time, so profile only what is read).
+ * kernel_times: copy the durations (ms) of kernel `which` for the submits recorded since enable,
+ * oldest first. */
 enum { CRSDR_KERNEL_REF_SPECTRUM = 0, CRSDR_KERNEL_XCORR_LAG = 1, CRSDR_KERNEL_PHASE_DOT = 2, CRSDR_KERNEL_ALIGN_QUANT = 3 };
-int crsdr_plan_enable_profiling(crsdr_plan *plan, int slots);
+#define CRSDR_PROFILE_ALL_KERNELS 0xFu
+#define CRSDR_PROFILE_SUBMIT (1u << 31)
+int crsdr_plan_enable_profiling(crsdr_plan *plan, int slots, uint32_t kernel_mask);
 int crsdr_plan_kernel_times(crsdr_plan *plan, int which, float *ms, int capacity, int *count);
 
 #ifdef __cplusplus
