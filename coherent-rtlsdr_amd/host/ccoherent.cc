@@ -63,7 +63,8 @@ bool ccoherent::step()
         ++c;
     }
     uint32_t flags = refnoise->isenabled() ? CRSDR_REFNOISE_ENABLED : 0;   // :271
-    if (lagqueuesize() <= 1) flags |= CRSDR_NO_LAG;            // :284
+    if (refdev->is_streaming_raw()) flags |= CRSDR_OFFSET_BINARY;          // ring holds raw uint8: XOR fused into the loads
+    if (lagqueuesize() <= 1) { flags |= CRSDR_NO_LAG; ++locked_steps; }   // :284 -- nobody asked: "locked" cadence
     if (crsdr_plan_submit(plan, rows.data(), CRSDR_MEM_HOST, readcnt.data(), mask.data(), seq++, flags) != CRSDR_OK ||
         crsdr_plan_fetch(plan, lag.data(), mag.data(), frac.data(), phasor.data(), packet.data()) != CRSDR_OK) {
         std::fprintf(stderr, "ccoherent: %s\n", crsdr_last_error());

@@ -31,6 +31,7 @@ class ccoherent {
     std::vector<int32_t> lag;
     std::vector<float> mag, frac, phasor;
     uint32_t seq;
+    uint32_t locked_steps = 0;
 public:
     std::atomic<bool> do_exit;
     ccoherent(crefsdr *, lvector<csdrdevice *> *, crefnoise *, int nfft, int mode = CRSDR_MODE_FAITHFUL);
@@ -44,5 +45,6 @@ public:
     void computelag();
     bool step();                      // one threadf iteration; false on a device-side error
     const std::vector<float> &get_frac() const { return frac; }
+    uint32_t get_locked_steps() const { return locked_steps; }   // blocks that ran the phase path only
 };
 #endif

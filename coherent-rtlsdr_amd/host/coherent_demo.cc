@@ -11,6 +11,7 @@
 #include <unistd.h>
 
 #include "ccoherent.h"
+#include "ccontrol.h"
 
 static int cdsp_selftest()
 {
@@ -48,7 +49,7 @@ int main(int argc, char **argv)
 {
     int nsig = 3, L = 8192, blocks = 12, mode = CRSDR_MODE_DIGITAL, dmax = -1;
     std::string dump, zmqaddr;
-    bool run_cdsp = false;
+    bool run_cdsp = false, servo = false, threads = false;
     int pace_ms = 0;
     for (int i = 1; i < argc; ++i) {
         std::string a = argv[i];
@@ -60,6 +61,8 @@ int main(int argc, char **argv)
         else if (a == "--faithful") mode = CRSDR_MODE_FAITHFUL;
         else if (a == "--dump" && i + 1 < argc) dump = argv[++i];
         else if (a == "--cdsp") run_cdsp = true;
+        else if (a == "--servo") servo = true;      // closed loop: ccontrol model slews the synthetic delays to zero (f3)
+        else if (a == "--threads") threads = true;  // streaming: producer thread per device, ccoherent thread, publish loop (f2)
         else if (a == "--zmq" && i + 1 < argc) zmqaddr = argv[++i];           // e.g. tcp://127.0.0.1:5555 (reference: tcp://*:5555)
         else if (a == "--zmq-debug" && i + 1 < argc) cpacketize::debugaddress = argv[++i];
         else if (a == "--pace-ms") val(pace_ms);
@@ -82,6 +85,68 @@ int main(int argc, char **argv)
         last_seq = h->globalseqn; last_N = h->N; last_L = h->L; last_bytes = bytes; ++packets;
     };
     ccoherent coherent(&ref, &devs, &refnoise, 8, mode);
+
+    if (threads) {
+        // f2: every device streams from its own producer thread into a ring (crtlsdr::asynch_threadf /
+        // swapbuffer / read / consume), the engine runs in its thread (ccoherent::start) and this thread
+        // is the publish loop of src/main.cc:277-279.  Per-row readcnt must be continuous in the packets.
+        std::vector<uint32_t> lastcnt(1 + nsig, 0);
+        size_t gaps = 0, npk = 0;
+        cpacketize::sink = [&](const int8_t *p, size_t, const std::complex<float> *, size_t) {
+            const uint32_t *rc = reinterpret_cast<const uint32_t *>(p + 16);
+            for (int c = 0; c <= nsig; ++c) { if (npk && rc[c] != lastcnt[c] + 1) ++gaps; lastcnt[c] = rc[c]; }
+            ++npk;
+        };
+        const int pace_us = pace_ms ? pace_ms * 1000 : 3000;
+        ref.start(pace_us, blocks);
+        for (auto &d : own) d->start(pace_us, blocks);
+        coherent.start();
+        for (int t = 0; t < blocks; ++t) cpacketize::send();
+        coherent.request_exit();
+        ref.stop();
+        for (auto &d : own) d->stop();
+        coherent.join();
+        const csynth_params *p = source.get_params();
+        for (int k = 0; k < nsig; ++k) fails += ((long)devs[k]->get_lagp()->lag != (long)p->d[k]);
+        uint32_t over = ref.get_overruns();
+        for (auto &d : own) over += d->get_overruns();
+        std::printf("streaming: %zu packets, %zu readcnt gaps, %u ring overruns, lags %s\n", npk, gaps, over, fails ? "MISMATCH" : "ok");
+        fails += (npk != (size_t)blocks) + (gaps != 0) + (over != 0);
+        cpacketize::cleanup();
+        std::printf("%s\n", fails ? "DEMO FAILED" : "DEMO OK");
+        return fails ? 1 : 0;
+    }
+    if (servo) {
+        // f3: closed loop.  Each device's ccontrol reads the lag the engine reports, slews the (modelled)
+        // resampler, re-measures, and marks the device synchronized at |lag| <= sync_threshold -- after which
+        // nobody requests lags and the engine runs its locked cadence.
+        std::vector<ccontrol> ctl;
+        for (auto &d : own) ctl.emplace_back(d.get());
+        int t = 0, synced_at = -1;
+        for (; t < blocks; ++t) {
+            source.advance();
+            if (!coherent.step()) { std::fprintf(stderr, "step failed\n"); return 2; }
+            cpacketize::send();
+            int nsync = 0;
+            for (size_t k = 0; k < ctl.size(); ++k) { ctl[k].on_block(); nsync += own[k]->get_synchronized(); }
+            if (nsync == nsig && synced_at < 0) synced_at = t;
+            if (synced_at >= 0 && t >= synced_at + 12) break;   // a dozen locked blocks for the EMA to settle
+        }
+        const csynth_params *p = source.get_params();
+        for (int k = 0; k < nsig; ++k) {
+            std::complex<float> ph = devs[k]->get_phasecorrect();
+            const double resid = std::arg(std::complex<double>(ph.real(), ph.imag()) * std::polar(1.0, std::atan2(p->s[k], p->c[k])));
+            const bool ok = own[k]->get_synchronized() && p->d[k] == 0 && devs[k]->get_lagp()->lag == 0.0f && std::fabs(resid) < 0.02;
+            std::printf("row %d: synchronized %d, residual delay %ld, last lag %.0f, residual phase %+.5f rad  %s\n", 1 + k,
+                        (int)own[k]->get_synchronized(), (long)p->d[k], devs[k]->get_lagp()->lag, resid, ok ? "ok" : "MISMATCH");
+            fails += !ok;
+        }
+        std::printf("servo: all synchronized after %d blocks, %u locked (phase-only) blocks of %d\n", synced_at, coherent.get_locked_steps(), t + 1);
+        fails += (synced_at < 0) + (coherent.get_locked_steps() < 10);
+        cpacketize::cleanup();
+        std::printf("%s\n", fails ? "DEMO FAILED" : "DEMO OK");
+        return fails ? 1 : 0;
+    }
 
     for (int t = 0; t < blocks; ++t) {
         source.advance();

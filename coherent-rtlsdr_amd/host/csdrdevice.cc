@@ -1,5 +1,6 @@
 // csdrdevice.cc -- see csdrdevice.h.
 #include "csdrdevice.h"
+#include <cmath>
 #include <cstring>
 
 csdrdevice::csdrdevice(uint32_t asyncbufn_, uint32_t blocksize_, uint32_t samplerate_, uint32_t fcenter_)
@@ -68,11 +69,79 @@ csyntheticsdr::csyntheticsdr(csynthsource *s, int row, uint32_t blocksize_, uint
     streaming = true;
     devname = "synthetic " + std::to_string(row);
 }
+csyntheticsdr::~csyntheticsdr() { stop(); }
+
 int8_t *csyntheticsdr::read()
 {
-    cur = src->row(rowindex);                                // crtlsdr::read src/crtlsdr.cc:195-203 without the cv wait
+    if (ring) {                                              // crtlsdr::read src/crtlsdr.cc:195-203
+        std::unique_lock<std::mutex> lock(mtx);
+        cv.wait(lock, [this] { return newdata.load() > 0 || do_exit.load(); });
+        if (newdata.load() > 0) newdata--;
+        cur = reinterpret_cast<int8_t *>(ring->getbufferptr());
+        cur_rcnt = ring->get_rcnt();
+        return cur;
+    }
+    cur = src->row(rowindex);
     inc_readcnt();
     return cur;
+}
+
+void csyntheticsdr::consume()
+{
+    if (ring) { std::lock_guard<std::mutex> lock(mtx); ring->consume(); }
+}
+
+void csyntheticsdr::asynch_threadf(csyntheticsdr *d)
+{
+    // the librtlsdr callback thread: asynch_callback -> swapbuffer -> cbuffer::setbufferptr
+    // (src/crtlsdr.cc:61-68,173-193, include/common.h:114-122), here fed by the synthetic source
+    std::vector<int8_t> tmp(d->blocksize);
+    for (int t = 0; (d->max_blocks == 0 || t < d->max_blocks) && !d->do_exit; ++t) {
+        csynth_make_row(d->src->get_params(), t, d->rowindex, -1.0, tmp.data());
+        {
+            std::unique_lock<std::mutex> lock(d->mtx);
+            if (d->ring->backlog() >= d->ring->capacity()) {  // consumer too slow: the oldest block is lost (README.md:42)
+                d->ring->consume();
+                d->overruns++;
+                if (d->newdata.load() > 0) d->newdata--;
+            }
+            uint8_t *w = d->ring->writeptr();
+            for (uint32_t i = 0; i < d->blocksize; ++i) w[i] = (uint8_t)tmp[i] ^ 0x80u;   // what the dongle delivers: offset binary
+            d->ring->commit(d->get_readcnt());
+            d->inc_readcnt();
+            d->newdata++;
+        }
+        d->cv.notify_all();
+        if (d->pace_us) std::this_thread::sleep_for(std::chrono::microseconds(d->pace_us));
+    }
+}
+
+void csyntheticsdr::start(int pace_us_, int max_blocks_)
+{
+    pace_us = pace_us_; max_blocks = max_blocks_;
+    ring.reset(new cbuffer(8, blocksize));                    // asyncbufn = 8, include/common.h:30
+    do_exit = false;
+    streaming = true;
+    producer = std::thread(asynch_threadf, this);
+}
+
+void csyntheticsdr::stop()
+{
+    do_exit = true;
+    cv.notify_all();
+    if (producer.joinable()) producer.join();
+}
+
+void csyntheticsdr::advance_resampler()
+{
+    // resampler running at fs (1 + p) for one block: the stream slips p * L samples against the reference
+    if (correction == 0.0f || rowindex == 0) return;
+    slip += (double)correction * (double)(blocksize >> 1);
+    const long whole = (long)(slip >= 0 ? std::floor(slip + 0.5) : -std::floor(-slip + 0.5));
+    if (whole != 0) {
+        src->set_delay(rowindex - 1, src->get_delay(rowindex - 1) - whole);   // a positive lag (late) is pulled forward
+        slip -= (double)whole;
+    }
 }
 const std::complex<float> *csyntheticsdr::convtofloat() { return cdsp::convtofloat(sfloat, cur, blocksize); }
 const std::complex<float> *csyntheticsdr::convtofloat(const std::complex<float> *p) { return cdsp::convtofloat(p, cur, blocksize); }

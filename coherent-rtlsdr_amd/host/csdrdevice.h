@@ -14,6 +14,7 @@
 #include <memory>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "cdsp.h"
@@ -86,21 +87,67 @@ public:
     void advance();                                   // generate the next block
     int8_t *row(int r) { return rows.data() + (size_t)r * 2 * L; }
     const csynth_params *get_params() const { return params; }
+    int64_t get_delay(int k) const { return params->d[k]; }
+    void set_delay(int k, int64_t d) { params->d[k] = d; }   // the resampler model of ccontrol moves this
     int blockindex() const { return block; }
     int get_L() const { return L; }
 };
 
-// signal channel (crtlsdr equivalent): samples land in sfloat[0..L)
+// ring of block buffers between a producer thread and the engine thread: the reference's cbuffer
+// (include/common.h:41-149) with librtlsdr's buffers replaced by owned storage.  Raw offset-binary
+// uint8 is kept as delivered; the XOR of cbuffer::setbufferptr -> cdsp::convtosigned (:114-122) is
+// fused into the GPU loads instead (CRSDR_OFFSET_BINARY).
+class cbuffer {
+    std::vector<std::vector<uint8_t>> slot;
+    std::vector<uint32_t> readcnt;
+    uint32_t N, wp, rp;
+public:
+    cbuffer(uint32_t n, uint32_t blocksize) : slot(n, std::vector<uint8_t>(blocksize)), readcnt(n, 0), N(n), wp(0), rp(0) {}
+    uint8_t *writeptr() { return slot[wp & (N - 1)].data(); }
+    void commit(uint32_t rcnt) { readcnt[wp & (N - 1)] = rcnt; ++wp; }
+    uint8_t *getbufferptr() { return slot[rp & (N - 1)].data(); }
+    uint32_t get_rcnt() { return readcnt[rp & (N - 1)]; }
+    void consume() { ++rp; }
+    uint32_t backlog() const { return wp - rp; }
+    uint32_t capacity() const { return N; }
+};
+
+// signal channel (crtlsdr equivalent): samples land in sfloat[0..L).
+// Two ways to run it: synchronous (read() takes the row of the source's current block -- the demo's
+// deterministic mode) or streaming (start(): a producer thread plays the librtlsdr callback thread,
+// src/crtlsdr.cc:32-68,173-193: it fills the ring with raw offset-binary uint8 blocks and wakes read()).
 class csyntheticsdr : public csdrdevice {
 protected:
     csynthsource *src;
     int rowindex;
     int8_t *cur;
+    // streaming mode
+    std::unique_ptr<cbuffer> ring;
+    std::thread producer;
+    std::mutex mtx;
+    std::condition_variable cv;
+    std::atomic<int> newdata{0};
+    std::atomic<bool> do_exit{false};
+    uint32_t cur_rcnt = 0, produced = 0, overruns = 0;
+    int pace_us = 0, max_blocks = 0;
+    static void asynch_threadf(csyntheticsdr *d);
+    // resampler model (ccontrol): accumulated slip in samples while a correction is set
+    float correction = 0.0f;
+    double slip = 0.0;
 public:
     csyntheticsdr(csynthsource *s, int row, uint32_t blocksize_, uint32_t samplerate_ = 2048000, uint32_t fcenter_ = 0);
+    ~csyntheticsdr() override;
     int8_t *read() override;
-    void consume() override {}
-    uint32_t get_readcntbuf() override { return get_readcnt(); }
+    void consume() override;
+    uint32_t get_readcntbuf() override { return ring ? cur_rcnt : get_readcnt(); }
+    void start(int pace_us_, int max_blocks_);          // crtlsdr::start src/crtlsdr.cc:24-30
+    void stop();                                        // :36-42
+    bool is_streaming_raw() const { return (bool)ring; } // rows are raw uint8 (offset binary) in streaming mode
+    uint32_t get_overruns() const { return overruns; }
+    int set_correction_f(float f) { correction = f; return 0; } // crtlsdr::set_correction_f src/crtlsdr.cc:167-170
+    float get_correction_f() const { return correction; }
+    void advance_resampler();                           // one block at the current correction: slip += p * L
+    int get_row() const { return rowindex; }
     const std::complex<float> *convtofloat() override;
     const std::complex<float> *convtofloat(const std::complex<float> *p) override;
 };

@@ -69,6 +69,30 @@ void csynth_params_destroy(csynth_params *p)
     free(p->d); free(p->c); free(p->s); free(p->g); free(p);
 }
 
+void csynth_make_row(const csynth_params *p, int block, int row, double noise_sigma, int8_t *out)
+{
+    const int L = p->L, dm = p->dmax, next = L + 2 * dm;
+    const double sn = noise_sigma < 0 ? SIGMA_NOISE : noise_sigma;
+    double *re = (double *)malloc(sizeof(double) * (size_t)next), *im = (double *)malloc(sizeof(double) * (size_t)next);
+    const uint64_t rs = mix(p->seed, 0xA0, (uint64_t)block);
+    for (int m = 0; m < next; ++m) { re[m] = gauss16(rs, 2 * (uint64_t)m); im[m] = gauss16(rs, 2 * (uint64_t)m + 1); }
+    if (row == 0) {
+        for (int n = 0; n < L; ++n) { out[2 * n] = quant(SIGMA_REF * re[dm + n]); out[2 * n + 1] = quant(SIGMA_REF * im[dm + n]); }
+    } else {
+        const int k = row - 1;
+        const uint64_t ws = mix(p->seed, 0xB000 + (uint64_t)k, (uint64_t)block);
+        const double gs = p->g[k] * SIGMA_REF, c = p->c[k], s = p->s[k];
+        for (int n = 0; n < L; ++n) {
+            const int m = n - (int)p->d[k] + dm;
+            const double rot_re = re[m] * c - im[m] * s, rot_im = re[m] * s + im[m] * c;
+            const double wr = gauss16(ws, 2 * (uint64_t)n), wi = gauss16(ws, 2 * (uint64_t)n + 1);
+            out[2 * n] = quant(gs * rot_re + sn * wr);
+            out[2 * n + 1] = quant(gs * rot_im + sn * wi);
+        }
+    }
+    free(re); free(im);
+}
+
 void csynth_make_block(const csynth_params *p, int block, double noise_sigma, int8_t *rows)
 {
     const int L = p->L, dm = p->dmax, next = L + 2 * dm;

@@ -20,6 +20,8 @@ csynth_params *csynth_params_create(int nsig, int L, uint64_t seed, int dmax /* 
 void csynth_params_destroy(csynth_params *p);
 /* rows: [1 + nsig][2L] int8, row 0 = reference noise.  noise_sigma < 0: default 10 LSB. */
 void csynth_make_block(const csynth_params *p, int block, double noise_sigma, int8_t *rows);
+/* one row of that block only (row 0 = reference noise, row k >= 1 = signal k-1): [2L] int8 */
+void csynth_make_row(const csynth_params *p, int block, int row, double noise_sigma, int8_t *out);
 uint64_t csynth_config_seed(int cfg); /* 0xC0FFEE + cfg */
 
 #ifdef __cplusplus

@@ -61,3 +61,24 @@ def test_host_demo_on_gpu(host_build, args, tmp_path, synth):
     rows = np.fromfile(dump, dtype=np.int8).reshape(1 + nsig, 16384)
     exp, _ = synth.make_block(nsig, 8192, synth.config_seed(1), 0)
     assert np.array_equal(rows, exp)
+
+
+@pytest.mark.gpu
+def test_servo_model_drives_track_to_locked(host_build):
+    # ccontrol's loop (descent = 2^-11 tanh(lag/100), hold 0.9 |lag/(p fs)|, sync_threshold) over
+    # the modelled resampler: every row ends synchronized with zero residual delay, the engine then runs its
+    # locked (phase-only) cadence, and the EMA phasor settles on exp(-j phi)
+    r = subprocess.run([os.path.join(host_build, "coherent_demo"), "--servo", "--dmax", "40", "--blocks", "400"],
+                       capture_output=True, text=True, timeout=300)
+    print(r.stdout, r.stderr)
+    assert r.returncode == 0 and "DEMO OK" in r.stdout, r.stdout + r.stderr
+
+
+@pytest.mark.gpu
+def test_streaming_devices_ring_and_readcnt_continuity(host_build):
+    # producer thread per device -> cbuffer ring (raw offset-binary uint8, XOR fused on the GPU)
+    # -> ccoherent thread -> publish loop; per-row readcnt continuous, no ring overruns, lags recovered
+    r = subprocess.run([os.path.join(host_build, "coherent_demo"), "--threads", "--blocks", "60", "--pace-ms", "4"],
+                       capture_output=True, text=True, timeout=300)
+    print(r.stdout, r.stderr)
+    assert r.returncode == 0 and "DEMO OK" in r.stdout, r.stdout + r.stderr
