@@ -93,3 +93,26 @@ def test_fft_linearity_and_roundtrip(b):
     assert np.linalg.norm(lhs - rhs) / np.linalg.norm(rhs) <= 1e-6
     back = b.fft(b.fft(x, -1), +1) / np.float32(n)
     assert np.linalg.norm(back - x) / np.linalg.norm(x) <= 1e-6
+
+
+def test_ragged_and_degenerate_sizes(b, oracle):
+    # per-op entry points on sizes that are not multiples of anything convenient, and the error codes for
+    # empty / invalid input (the reference's wrappers would pass such n straight to VOLK)
+    rng = np.random.default_rng(7)
+    for n in (1, 2, 3, 17, 63, 65, 1000, 4097):
+        i8 = rng.integers(-128, 128, n, dtype=np.int8)
+        if n % 2 == 0:
+            assert np.array_equal(b.convtofloat(i8).view(np.float32), oracle.convtofloat(i8).view(np.float32))
+        x = _crand(rng, n)
+        assert np.array_equal(b.magsquared(x), oracle.magsquared(x))
+        assert np.array_equal(b.convto8bit(x), oracle.convto8bit(x))
+        assert np.array_equal(b.scalarmul(x, 1j).view(np.float32), oracle.scalarmul(x, 1j).view(np.float32))
+        m = rng.random(n).astype(np.float32)
+        assert b.indexofmax(m) == oracle.indexofmax(m)
+    for bad in (lambda: b.convtofloat(np.zeros(0, dtype=np.int8)), lambda: b.magsquared(np.zeros(0, dtype=np.complex64)),
+                lambda: b.convtosigned(np.zeros(12, dtype=np.uint8)),           # n % 8 != 0
+                lambda: b.fft(np.zeros(32768, dtype=np.complex64)),             # beyond the LDS-resident per-op size
+                lambda: b.fft(np.zeros(8, dtype=np.complex64))):                # below the smallest transform
+        with pytest.raises(b.CrsdrError) as e:
+            bad()
+        assert e.value.code == -1

@@ -290,3 +290,30 @@ def test_cfg5_long_blocks_full_size(b, oracle, model, synth):
     assert np.array_equal(got2["lag"][1:], params.d)
     assert np.abs(np.angle(got2["phasor"][1:] * np.exp(1j * params.phi))).max() < 0.8   # converging: 1/4 residual after 2 blocks
     plan.close()
+
+
+def test_full_scale_dc_rows_do_not_overflow(b, oracle):
+    # worst case for the un-scaled integer transform chain: every sample -128-128j in every row.  The
+    # correlation is a triangle peaking at zero lag; |ifft|^2 reaches ~1e33 (< FLT_MAX) before the final
+    # 1/127^2 scale.  No inf / NaN, lag 0, mag equal to the oracle's.
+    nsig, L = 3, 8192
+    rows = np.full((nsig + 1, 2 * L), -128, dtype=np.int8)
+    got = b.Plan(nsig + 1, 2 * L, b.MODE_DIGITAL).block(rows)
+    exp = oracle.Engine(nsig + 1, 2 * L, oracle.DIGITAL).block(rows)
+    assert np.all(np.isfinite(got["mag"])) and np.all(np.isfinite(got["frac"]))
+    assert np.array_equal(got["lag"], exp["lag"]) and np.all(got["lag"] == 0)
+    assert np.allclose(got["mag"], exp["mag"], rtol=1e-4)
+    assert np.array_equal(got["matrix"], exp["matrix"])
+
+
+def test_maximum_block_size_plan(b, synth):
+    # largest supported block: B = 2^22 (N1 = 256 column transforms): delays recovered exactly
+    nsig, L = 1, 1 << 21
+    params = synth.RowParams(nsig, L, 9, dmax=5000)
+    rows, _ = synth.make_block(nsig, L, 9, 0, params=params)
+    got = b.Plan(nsig + 1, 2 * L, b.MODE_DIGITAL).block(rows)
+    assert np.array_equal(got["lag"][1:], params.d)
+    with pytest.raises(b.CrsdrError):
+        b.Plan(2, 1 << 23)                                        # beyond the supported range
+    with pytest.raises(b.CrsdrError):
+        b.Plan(2, 1 << 21, max_batch=2)                           # long blocks are submitted one at a time
