@@ -255,6 +255,18 @@ def main():
                                              "traffic": _committed_traffic("k_align_quant")},
                                 "hbm_read_frac": (nrows * B) * (n_l / dt_l) / (world * HBM_PEAK_GBS * 1e9)}
 
+    # ---- extra: downstream covariance of one aligned matrix on the matrix cores ----------
+    if not args.no_extras and world == 1:
+        rxx = torch.empty((nsig, nsig, 2), dtype=torch.float32, device=dev)
+        mptr = pk_view[0][0].data_ptr() + plan.matrix_offset
+        b.covariance_device(rxx.data_ptr(), mptr, nrows, B)
+        t0 = time.perf_counter()
+        for _ in range(10):
+            b.covariance_device(rxx.data_ptr(), mptr, nrows, B)
+        dtc = (time.perf_counter() - t0) / 10
+        result["covariance"] = {"ms": 1e3 * dtc, "int8_TOPS": 3 * 2 * nsig * nsig * B / dtc / 1e12,
+                                "note": "Rxx = X^H X / L of the 1024 signal rows, 3 int8 MFMA products, host-synchronous call"}
+
     # ---- extra: host-buffer (PCIe-inclusive) rate -- reported for DESIGN.md, never `value` -----------
     if not args.no_extras and world == 1:
         hp = b.Plan(nrows, B, mode, device=local_rank, max_batch=T)

@@ -28,7 +28,7 @@ ABI_SYMBOLS = [
     "crsdr_plan_submit", "crsdr_plan_fetch", "crsdr_plan_sync", "crsdr_plan_packet_bytes",
     "crsdr_plan_matrix_offset", "crsdr_plan_device_buffers", "crsdr_plan_bind_packet",
     "crsdr_plan_last_elapsed_ms", "crsdr_plan_enable_profiling", "crsdr_plan_kernel_times",
-    "crsdr_plan_submit_batch", "crsdr_plan_fetch_block", "crsdr_plan_packet_stride",
+    "crsdr_plan_submit_batch", "crsdr_plan_fetch_block", "crsdr_plan_packet_stride", "crsdr_covariance",
 ]
 KERNEL_REF_SPECTRUM, KERNEL_XCORR_LAG, KERNEL_PHASE_DOT, KERNEL_ALIGN_QUANT = 0, 1, 2, 3
 
@@ -78,6 +78,7 @@ def lib():
     L.crsdr_conjugatemul.argtypes = [f32p, f32p, f32p, C.c_int]
     L.crsdr_indexofmax.argtypes = [u32p, f32p, C.c_int]
     L.crsdr_fft.argtypes = [f32p, f32p, C.c_int, C.c_int, C.c_int]
+    L.crsdr_covariance.argtypes = [f32p, i8p, C.c_int, C.c_int, C.c_int]
     L.crsdr_plan_create.argtypes = [C.POINTER(vp), C.POINTER(PlanDesc)]
     L.crsdr_plan_destroy.argtypes = [vp]
     L.crsdr_plan_reset.argtypes = [vp]
@@ -189,6 +190,21 @@ def fft(x, sign=-1):
     out = np.empty_like(x)
     _check(lib().crsdr_fft(_p(out.view(np.float32), C.c_float), _p(xf, C.c_float), n, sign, x.size // n))
     return out
+
+
+def covariance(matrix):
+    """Rxx of the signal rows of an aligned int8 matrix [nrows][B] (beamformer's first step)."""
+    m = np.ascontiguousarray(matrix, dtype=np.int8)
+    nrows, B = m.shape
+    out = np.empty((nrows - 1, nrows - 1), dtype=np.complex64)
+    _check(lib().crsdr_covariance(_p(out.view(np.float32), C.c_float), _p(m, C.c_int8), nrows, B, MEM_HOST))
+    return out
+
+
+def covariance_device(rxx_ptr: int, matrix_ptr: int, nrows: int, B: int):
+    """Same on device memory (both pointers on the current device); returns after the kernels finished."""
+    _check(lib().crsdr_covariance(C.cast(C.c_void_p(int(rxx_ptr)), C.POINTER(C.c_float)),
+                                  C.cast(C.c_void_p(int(matrix_ptr)), C.POINTER(C.c_int8)), nrows, B, MEM_DEVICE))
 
 
 # ---- batched plan ---------------------------------------------------------------------------------

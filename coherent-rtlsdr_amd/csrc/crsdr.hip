@@ -393,6 +393,33 @@ extern "C" int crsdr_fft(float *out, const float *in, int n, int sign, int howma
     return CRSDR_OK;
 }
 
+// ---- (iii) downstream helper: sample covariance of the aligned matrix on the matrix cores ----
+extern "C" int crsdr_covariance(float *rxx, const int8_t *matrix, int nrows, int blocksize, int mem_kind)
+{
+    if (!rxx || !matrix || nrows < 2 || blocksize < 32 || (blocksize % 32)) return fail(CRSDR_EINVAL, "covariance: need rxx, matrix, nrows >= 2, blocksize % 32 == 0");
+    if (mem_kind != CRSDR_MEM_HOST && mem_kind != CRSDR_MEM_DEVICE) return fail(CRSDR_EINVAL, "covariance: mem_kind = %d", mem_kind);
+    { int rc_ = require_device(); if (rc_) return rc_; }
+    std::lock_guard<std::mutex> lock_(g_op.mu);
+    const size_t mb = (size_t)nrows * (size_t)blocksize, nsig = (size_t)nrows - 1, rb = sizeof(float2) * nsig * nsig;
+    const int8_t *d_m = matrix;
+    float2 *d_r = (float2 *)rxx;
+    OP_RESERVE(2, sizeof(int2) * (size_t)nrows);
+    if (mem_kind == CRSDR_MEM_HOST) {
+        OP_RESERVE(0, mb); OP_RESERVE(1, rb);
+        HIP_TRY(hipMemcpy(g_op.buf[0], matrix, mb, hipMemcpyHostToDevice));
+        d_m = (const int8_t *)g_op.buf[0];
+        d_r = (float2 *)g_op.buf[1];
+    }
+    hipLaunchKernelGGL(cov::k_row_sums, dim3(nrows), dim3(256), 0, 0, d_m, blocksize, (int2 *)g_op.buf[2]);
+    HIP_TRY(hipGetLastError());
+    const unsigned tiles = (unsigned)((nsig + 63) / 64);
+    hipLaunchKernelGGL(cov::k_covariance, dim3(tiles, tiles), dim3(256), 0, 0, d_m, nrows, blocksize, (const int2 *)g_op.buf[2], d_r);
+    HIP_TRY(hipGetLastError());
+    if (mem_kind == CRSDR_MEM_HOST) HIP_TRY(hipMemcpy(rxx, d_r, rb, hipMemcpyDeviceToHost));
+    else HIP_TRY(hipDeviceSynchronize());
+    return CRSDR_OK;
+}
+
 // ================================================================================================
 // (ii) batched plan
 // ================================================================================================

@@ -23,6 +23,7 @@
 #include "plan_args.hpp"
 #include "xcorr14.hpp"
 #include "longblock.hpp"
+#include "covariance.hpp"
 #include <stdint.h>
 
 namespace crsdr {

@@ -223,6 +223,19 @@ enum { CRSDR_KERNEL_REF_SPECTRUM = 0, CRSDR_KERNEL_XCORR_LAG = 1, CRSDR_KERNEL_P
 int crsdr_plan_enable_profiling(crsdr_plan *plan, int slots, uint32_t kernel_mask);
 int crsdr_plan_kernel_times(crsdr_plan *plan, int which, float *ms, int capacity, int *count);
 
+/* ------------------------------------------------------------------------------------------
+ * (iii) downstream helper: what the reference's beamformer computes first from a packet
+ * ---------------------------------------------------------------------------------------- */
+
+/* Sample covariance of the signal channels of one aligned receive matrix, as
+ * beamformclient/heatmap2d2.cpp:189-199 forms it:  X(n, c) = (I + jQ)/127 of channel c >= 1 (row 0,
+ * the reference channel, is dropped), per-channel mean removed,  Rxx = (1/L) X^H X.
+ *   matrix [nrows][blocksize] int8 -- the data part of a packet (packet + crsdr_plan_matrix_offset)
+ *   rxx    [(nrows-1)][(nrows-1)][2] float, row-major, rxx[a][b] = (1/L) sum_n conj(x_a[n]) x_b[n] - conj(mean_a) mean_b
+ * Runs as an int8 GEMM on the matrix cores (v_mfma_i32_32x32x32_i8), exact integer sums, fp64 epilogue.
+ * blocksize % 32 == 0.  mem_kind: CRSDR_MEM_HOST (copied) or CRSDR_MEM_DEVICE (both pointers on the device). */
+int crsdr_covariance(float *rxx, const int8_t *matrix, int nrows, int blocksize, int mem_kind);
+
 #ifdef __cplusplus
 }
 #endif

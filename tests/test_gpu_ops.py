@@ -116,3 +116,40 @@ def test_ragged_and_degenerate_sizes(b, oracle):
         with pytest.raises(b.CrsdrError) as e:
             bad()
         assert e.value.code == -1
+
+
+@pytest.mark.parametrize("nsig,L", [(3, 256), (21, 8192), (64, 1024), (100, 512), (257, 2048)])
+def test_covariance_matches_the_beamformer_formula(b, synth, nsig, L):
+    # Rxx = (1/L) X^H X with the per-channel mean removed, X = int8/127 over the signal channels
+    # (beamformclient/heatmap2d2.cpp:189-199).  The GPU sums are exact integers (int8 MFMA), so the only
+    # error is the final fp32 rounding: relative 1e-6 of the largest entry.
+    rows, _ = synth.make_block(nsig, L, 1000 + nsig, 0, dmax=L // 8)
+    rows = rows.copy()
+    rows[1] = np.clip(rows[1].astype(np.int16) + 17, -128, 127).astype(np.int8)      # a channel with a DC offset
+    got = b.covariance(rows)
+    x = rows[1:].astype(np.float64) / 127.0
+    X = (x[:, 0::2] + 1j * x[:, 1::2]).T                      # X(n, c)
+    X = X - X.mean(axis=0, keepdims=True)
+    ref = (X.conj().T @ X) / L
+    assert got.shape == (nsig, nsig)
+    assert np.abs(got - ref).max() <= 1e-6 * np.abs(ref).max()
+    assert np.allclose(got, got.conj().T, atol=1e-6 * np.abs(ref).max())     # Hermitian
+
+
+def test_covariance_of_the_aligned_matrix_is_rank_one_dominated(b, synth):
+    # end to end: after digital alignment every channel is a scaled copy of the reference noise plus
+    # independent noise, so Rxx has one dominant eigenvalue whose eigenvector has (nearly) equal phases --
+    # the structure the MUSIC scan of the reference's beamformer relies on
+    nsig, L = 21, 8192
+    seed = synth.config_seed(2)
+    params = synth.RowParams(nsig, L, seed)
+    plan = b.Plan(nsig + 1, 2 * L, b.MODE_DIGITAL)
+    for t in range(10):
+        rows, _ = synth.make_block(nsig, L, seed, t, params=params)
+        out = plan.block(rows, seq=t)
+    R = b.covariance(out["matrix"]).astype(np.complex128)
+    w, v = np.linalg.eigh(R)
+    assert w[-1] > 5 * w[-2]
+    ph = np.angle(v[:, -1] * np.conj(v[0, -1]))
+    assert np.abs(ph).max() < 0.05
+    plan.close()
