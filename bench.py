@@ -40,9 +40,9 @@ def parse():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--nsig", type=int, default=1024, help="signal rows (channels) in the receive matrix")
     ap.add_argument("--L", type=int, default=8192, help="complex samples per row per block")
-    ap.add_argument("--nbuf", type=int, default=16, help="distinct resident input blocks rotated through")
+    ap.add_argument("--nbuf", type=int, default=32, help="distinct resident input blocks rotated through")
     ap.add_argument("--batch", type=int, default=0, help="consecutive blocks per submit (one launch set per batch); "
-                    "0 = 8 x min(n_gpus, 4): with the rows sharded a rank's batch shrinks, so it carries more blocks")
+                    "0 = 16 on one GPU, 32 on several: with the rows sharded a rank's batch shrinks, so it carries more blocks")
     ap.add_argument("--mode", choices=["digital", "faithful"], default="digital")
     ap.add_argument("--cfg5", action="store_true", help="BASELINE config 5 instead: 1 + 21 rows x 2^20 samples (long-block path)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -91,7 +91,7 @@ def main():
     mode = b.MODE_DIGITAL if args.mode == "digital" else b.MODE_FAITHFUL
 
     # ---- synthetic resident input: nbuf distinct blocks, each rank fills row 0 + its slab ----------
-    T = max(1, min(args.batch if args.batch > 0 else 8 * min(world, 4), args.steps, 64))
+    T = max(1, min(args.batch if args.batch > 0 else (16 if world == 1 else 32), args.steps, 64))
     nbuf = max(2 * T if world > 1 else T, (args.nbuf // T) * T)   # whole batches, contiguous in HBM
     seed = synth.config_seed(4)
     params = synth.RowParams(nsig, L, seed)

@@ -38,6 +38,30 @@ def _mix(seed: int, a: int, b: int) -> int:
     return int(splitmix64(s, np.array([b], dtype=np.uint64))[0])
 
 
+def _splitmix64_vec(seeds: np.ndarray, idx: np.ndarray) -> np.ndarray:
+    """SplitMix64 with one seed per row: seeds [K] uint64, idx [M] -> [K, M]."""
+    with np.errstate(over="ignore"):
+        z = seeds.astype(np.uint64)[:, None] + (idx.astype(np.uint64)[None, :] + np.uint64(1)) * _GOLD
+        z = (z ^ (z >> np.uint64(30))) * _M1
+        z = (z ^ (z >> np.uint64(27))) * _M2
+        z = z ^ (z >> np.uint64(31))
+    return z
+
+
+def _mix_vec(seed: int, a: np.ndarray, b: int) -> np.ndarray:
+    """_mix for an array of `a` values -> [K] uint64 stream seeds."""
+    s1 = splitmix64(seed, np.asarray(a, dtype=np.uint64))
+    return _splitmix64_vec(s1, np.array([b], dtype=np.uint64))[:, 0]
+
+
+def gauss16_rows(seeds: np.ndarray, count: int) -> np.ndarray:
+    """[K, count] approximately N(0,1) doubles, row k from stream seeds[k], counters 0..count-1."""
+    z = _splitmix64_vec(seeds, np.arange(count, dtype=np.uint64))
+    m = np.uint64(0xFFFF)
+    acc = ((z & m) + ((z >> np.uint64(16)) & m) + ((z >> np.uint64(32)) & m) + (z >> np.uint64(48))).astype(np.int64)
+    return (acc - 131070).astype(np.float64) * INV_SIGMA16
+
+
 def gauss16(seed: int, start: int, count: int) -> np.ndarray:
     """`count` approximately N(0,1) doubles from counters start..start+count-1."""
     z = splitmix64(seed, np.arange(start, start + count, dtype=np.uint64))
@@ -101,14 +125,24 @@ def make_block(nsig: int, L: int, seed: int, block: int = 0, params: RowParams |
     rows = np.empty((1 + nsig, 2 * L), dtype=np.int8)
     rows[0] = _quant_i8(SIGMA_REF * r_ext[dm: dm + L])
     n = np.arange(L)
-    for k in range(nsig):
-        rk = r_ext[n - int(p.d[k]) + dm]
-        rot_re = rk.real * p.c[k] - rk.imag * p.s[k]
-        rot_im = rk.real * p.s[k] + rk.imag * p.c[k]
-        w = cgauss(_mix(seed, 0xB000 + k, block), 0, L)
-        gs = p.g[k] * SIGMA_REF
-        x = (gs * rot_re + noise_sigma * w.real) + 1j * (gs * rot_im + noise_sigma * w.imag)
-        rows[1 + k] = _quant_i8(x)
+    # rows are independent given r_ext: vectorised over chunks of rows (same arithmetic, same order of
+    # operations per element as the scalar recipe in host/csynth.c)
+    chunk = max(1, min(nsig, (1 << 18) // max(L, 1)))
+    for k0 in range(0, nsig, chunk):
+        ks = np.arange(k0, min(nsig, k0 + chunk))
+        idx = n[None, :] - p.d[ks][:, None] + dm
+        rk_re, rk_im = r_ext.real[idx], r_ext.imag[idx]
+        c, sn, g = p.c[ks][:, None], p.s[ks][:, None], p.g[ks][:, None]
+        rot_re = rk_re * c - rk_im * sn
+        rot_im = rk_re * sn + rk_im * c
+        seeds = _mix_vec(seed, 0xB000 + ks, block)
+        wg = gauss16_rows(seeds, 2 * L)
+        gs = g * SIGMA_REF
+        xr = gs * rot_re + noise_sigma * wg[:, 0::2]
+        xi = gs * rot_im + noise_sigma * wg[:, 1::2]
+        out = rows[1 + k0: 1 + k0 + ks.size]
+        out[:, 0::2] = np.clip(np.rint(xr), -128, 127).astype(np.int8)
+        out[:, 1::2] = np.clip(np.rint(xi), -128, 127).astype(np.int8)
     if offset_binary:
         return (rows.view(np.uint8) ^ np.uint8(0x80)), p
     return rows, p
