@@ -11,7 +11,7 @@ struct XcorrArgs {
     size_t block_stride;    // bytes
     const float2 *refspec;  // [T][B] conj reference spectra of this batch (kernel-specific order)
     const uint8_t *lag_mask; // [nrows] or nullptr = every owned row
-    int row_begin, nrows, nblocks;
+    int row_begin, nrows, nblocks, stagger;
     uint32_t xor80;
     int32_t *lag;           // [T][nrows] per-block outputs
     float *mag, *frac;

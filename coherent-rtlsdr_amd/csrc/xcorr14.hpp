@@ -288,6 +288,12 @@ __global__ __launch_bounds__(THREADS, 2) void k_xcorr_lag14(XcorrArgs a, const f
     tw_load(wB, twB, TWB_STRIDE, tid & 15);
     __syncthreads();
     CRSDR_STAMP(2);
+    // stagger: the two waves of a SIMD run the same program and would hit their LDS bursts and VALU
+    // stretches together; holding waves 4..7 back by ~500 cycles at the start of the wave-local section
+    // lets one wave's exchange overlap the other's butterflies (measured: -2..3 % K1 time at stagger = 1,
+    // +4 % at 8; MI355X_MICROARCH.md "Two waves per SIMD", item 9)
+    if (a.stagger > 0 && (tid >> 8))
+        for (int i = 0; i < a.stagger; ++i) __builtin_amdgcn_s_sleep(8);
     pass1_forward(A, wB, tid);
     wave_lds_sync();
     CRSDR_STAMP(3);
