@@ -198,7 +198,7 @@ static hipError_t launch_long_fwd_cols(hipStream_t s, int nrows_launch, const in
     auto kern = lb::k_long_fwd_cols<LOG2N1, IS_REF>;
     hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lb::LDS_BYTES);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(kern, dim3(1 << LOG2N1, nrows_launch), dim3(lb::THREADS), lb::LDS_BYTES, s, rows, row_begin, xor80, tw, Y);
+    hipLaunchKernelGGL(kern, dim3(lb::ntiles(LOG2N1), nrows_launch), dim3(lb::THREADS), lb::LDS_BYTES, s, rows, row_begin, xor80, tw, Y);
     return hipGetLastError();
 }
 // stage B: the 16384-point row transforms run on the 32x32x16 structure of xcorr14.hpp
@@ -217,7 +217,7 @@ static hipError_t launch_long_inv_cols(hipStream_t s, int nrows_launch, const fl
     auto kern = lb::k_long_inv_cols<LOG2N1>;
     hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lb::LDS_BYTES);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(kern, dim3(1 << LOG2N1, nrows_launch), dim3(lb::THREADS), lb::LDS_BYTES, s, Z, tw, part);
+    hipLaunchKernelGGL(kern, dim3(lb::ntiles(LOG2N1), nrows_launch), dim3(lb::THREADS), lb::LDS_BYTES, s, Z, tw, part);
     return hipGetLastError();
 }
 
@@ -517,7 +517,7 @@ static int plan_alloc(crsdr_plan *p)
         if ((rc = make_twiddle_table((double)n1, n1, 1, &p->d_tw1))) return rc;
         HIP_TRY(hipMalloc((void **)&p->d_Y, sizeof(float2) * Bz * (size_t)p->row_count));
         HIP_TRY(hipMalloc((void **)&p->d_Yref, sizeof(float2) * Bz));
-        HIP_TRY(hipMalloc((void **)&p->d_part, sizeof(lb::LongPartial) * n1 * (size_t)p->row_count));
+        HIP_TRY(hipMalloc((void **)&p->d_part, sizeof(lb::LongPartial) * (size_t)lb::ntiles(p->log2n1) * (size_t)p->row_count));
     }
     const size_t n = (size_t)p->nrows, T = (size_t)p->max_batch;
     const size_t rowbytes = n * (size_t)p->B;
@@ -755,7 +755,7 @@ extern "C" int crsdr_plan_submit_batch(crsdr_plan *p, const void *rows, int mem_
         HIP_TRY(CRSDR_DISPATCH_N1(l1, (launch_long_fwd_cols<LG, false>(S, p->row_count, d_in, p->row_begin, xor80, tw, p->d_Y))));
         HIP_TRY(launch_long_rows<false>(S, n1, p->row_count, p->d_Y, p->d_twA, p->d_twB, p->d_refspec[0]));
         HIP_TRY(CRSDR_DISPATCH_N1(l1, (launch_long_inv_cols<LG>(S, p->row_count, p->d_Y, tw, p->d_part))));
-        hipLaunchKernelGGL(lb::k_long_finalize, dim3(p->row_count), dim3(256), 0, S, p->d_Y, p->d_part, tw, n1, xa);
+        hipLaunchKernelGGL(lb::k_long_finalize, dim3(p->row_count), dim3(256), 0, S, p->d_Y, p->d_part, tw, n1, lb::ntiles(l1), xa);
         HIP_TRY(hipGetLastError());
         if (pe1) HIP_TRY(hipEventRecord(pe1[1], S));
     } else if (any_lag) {

@@ -23,7 +23,11 @@
 namespace crsdr {
 namespace lb {
 
-constexpr int LOG2N2 = 14, N2 = 1 << LOG2N2, THREADS = 1024, TILE = 16384; // elements per LDS tile
+constexpr int LOG2N2 = 14, N2 = 1 << LOG2N2;
+// column-pass tile: 8192 elements = 64 KiB of LDS and 512 threads, so two workgroups share a CU and one's
+// HBM traffic overlaps the other's column transforms (16384-element tiles, one workgroup per CU: +45 % time)
+constexpr int LOG2TILE = 13, TILE = 1 << LOG2TILE, THREADS = 512;
+__host__ __device__ constexpr int ntiles(int log2n1) { return 1 << (LOG2N2 + log2n1 - LOG2TILE); } // column tiles per row
 constexpr int FBITS = 11;                                                    // fine twiddle table: 2^11 entries
 constexpr size_t LDS_BYTES = sizeof(float2) * TILE + 512;
 
@@ -53,7 +57,7 @@ __device__ __forceinline__ void col_fft(float2 *T, const float2 *__restrict__ tw
 {
     using G = FftGeom<LOG2N1>;
     if constexpr (P < G::NPASS) {
-        constexpr int LOG2C = LOG2N2 - LOG2N1, C = 1 << LOG2C;
+        constexpr int LOG2C = LOG2TILE - LOG2N1, C = 1 << LOG2C;
         constexpr int LR = G::log2r(P), R = 1 << LR, LM = G::log2m(P), M = 1 << LM;
         constexpr int NG = TILE / R;
         for (int g = tid; g < NG; g += THREADS) {
@@ -77,13 +81,13 @@ __device__ __forceinline__ void col_fft(float2 *T, const float2 *__restrict__ tw
 }
 
 // ---- A: int8 -> column FFTs -> x W_B^(n2 k1) -> Y[k1][n2] -------------------------------------------
-// grid (N1 tiles, rows); tile = columns [tile*C, (tile+1)*C).  Signal rows carry samples at n < L
+// grid (ntiles, rows); tile = columns [tile*C, (tile+1)*C), C = TILE / N1.  Signal rows carry samples at n < L
 // (n1 < N1/2), the ref row at n >= L (src/crtlsdr.cc:205-207,215-218).
 template <int LOG2N1, bool IS_REF>
 __global__ __launch_bounds__(THREADS) void k_long_fwd_cols(const int8_t *__restrict__ rows, int row_begin, uint32_t xor80,
                                                            LongTw tw, float2 *__restrict__ Y)
 {
-    constexpr int N1 = 1 << LOG2N1, LOG2C = LOG2N2 - LOG2N1, C = 1 << LOG2C, H = N1 / 2;
+    constexpr int N1 = 1 << LOG2N1, LOG2C = LOG2TILE - LOG2N1, C = 1 << LOG2C, H = N1 / 2;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float2 *T = reinterpret_cast<float2 *>(smem);
     const int tid = threadIdx.x, tile = blockIdx.x;
@@ -120,7 +124,7 @@ struct LongPartial {
 template <int LOG2N1>
 __global__ __launch_bounds__(THREADS) void k_long_inv_cols(const float2 *__restrict__ Z, LongTw tw, LongPartial *__restrict__ part)
 {
-    constexpr int N1 = 1 << LOG2N1, LOG2C = LOG2N2 - LOG2N1, C = 1 << LOG2C;
+    constexpr int N1 = 1 << LOG2N1, LOG2C = LOG2TILE - LOG2N1, C = 1 << LOG2C;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float2 *T = reinterpret_cast<float2 *>(smem);
     LongPartial *wred = reinterpret_cast<LongPartial *>(smem + sizeof(float2) * TILE);
@@ -154,7 +158,7 @@ __global__ __launch_bounds__(THREADS) void k_long_inv_cols(const float2 *__restr
         LongPartial b = wred[0];
         for (int w = 1; w < THREADS / 64; ++w)
             if (wred[w].m > b.m || (wred[w].m == b.m && wred[w].idx < b.idx)) b = wred[w];
-        part[(size_t)blockIdx.y * N1 + tile] = b;
+        part[(size_t)blockIdx.y * gridDim.x + tile] = b;
     }
 }
 
@@ -162,7 +166,7 @@ __global__ __launch_bounds__(THREADS) void k_long_inv_cols(const float2 *__restr
 // y[n] for a single n is an N1-term sum over the column of Z that holds it:
 //   y[n1 N2 + n2] = sum_k1 Z[k1][n2] conj(W_B^(n2 k1)) conj(W_N1^(n1 k1))
 __global__ __launch_bounds__(256) void k_long_finalize(const float2 *__restrict__ Z, const LongPartial *__restrict__ part, LongTw tw,
-                                                       int N1, XcorrArgs a)
+                                                       int N1, int ntile, XcorrArgs a)
 {
     __shared__ LongPartial sp[256];
     __shared__ float snb[2][2 * 256];
@@ -170,8 +174,8 @@ __global__ __launch_bounds__(256) void k_long_finalize(const float2 *__restrict_
     if (xcorr_skip(a, row, t, tid)) return;
     const size_t B = (size_t)N1 * N2;
     LongPartial b = {-1.0f, 0x7fffffff};
-    for (int i = tid; i < N1; i += 256) {
-        const LongPartial p = part[(size_t)blockIdx.x * N1 + i];
+    for (int i = tid; i < ntile; i += 256) {
+        const LongPartial p = part[(size_t)blockIdx.x * ntile + i];
         if (p.m > b.m || (p.m == b.m && p.idx < b.idx)) b = p;
     }
     sp[tid] = b;
