@@ -164,6 +164,15 @@ def main():
             dt = float(t.item())
         return dt
 
+    # communicator set-up (not a step): RCCL opens its point-to-point channels lazily, on the first send/recv
+    # of each rank pair -- do that here, with the exchange pattern of one full batch on a still-empty packet
+    # set, so that a warm-up shorter than one batch does not leave connection set-up inside the timed region
+    if world > 1 and not rehearsal:
+        for w in sharding.gather_batch(pk_view[NSETS - 1], nrows, B, slab, 0):
+            w.wait()
+        torch.cuda.synchronize()
+        dist.barrier()
+
     # ---- warm-up, then the timed region with per-kernel HIP events on the launch streams ----------
     run_steps(args.warmup)
     fence()
@@ -232,6 +241,7 @@ def main():
                            "hbm_read_frac": A_block * blocks_per_s / (world * HBM_PEAK_GBS * 1e9)},
             "kernel_ms": {k: (float(np.mean(v)) if len(v) else None) for k, v in k_ms.items()},
             "lags_exact": lags_ok, "matrix_assembled": assembled_ok if world > 1 else None,
+            "env": _env(torch, dev),
         }
 
     # ---- extras: locked steady state (phase path only) ---------------------------------------------
@@ -308,6 +318,23 @@ def _make_slab(synth, params, nsig, L, seed, t, slab):
     rows[0] = part[0]
     rows[slab.row_begin: slab.row_begin + slab.row_count] = part[1:]
     return rows, None
+
+
+def _env(torch, dev):
+    """GPU and host the numbers were taken on (clocks recorded)."""
+    p = torch.cuda.get_device_properties(dev)
+    cpu = None
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                cpu = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    clk = getattr(p, "clock_rate", None)
+    return {"gpu": p.name, "arch": getattr(p, "gcnArchName", None), "cus": p.multi_processor_count,
+            "gpu_max_clock_mhz": clk / 1e3 if clk else None, "hbm_gib": round(p.total_memory / 2**30, 1),
+            "cpu": cpu, "host_cores": len(os.sched_getaffinity(0)), "torch": torch.__version__}
 
 
 def _committed_traffic(kernel):

@@ -29,6 +29,7 @@ ABI_SYMBOLS = [
     "crsdr_plan_matrix_offset", "crsdr_plan_device_buffers", "crsdr_plan_bind_packet",
     "crsdr_plan_last_elapsed_ms", "crsdr_plan_enable_profiling", "crsdr_plan_kernel_times",
     "crsdr_plan_submit_batch", "crsdr_plan_fetch_block", "crsdr_plan_packet_stride", "crsdr_covariance",
+    "crsdr_noisesubspace", "crsdr_pmusic2d",
 ]
 KERNEL_REF_SPECTRUM, KERNEL_XCORR_LAG, KERNEL_PHASE_DOT, KERNEL_ALIGN_QUANT = 0, 1, 2, 3
 
@@ -79,6 +80,8 @@ def lib():
     L.crsdr_indexofmax.argtypes = [u32p, f32p, C.c_int]
     L.crsdr_fft.argtypes = [f32p, f32p, C.c_int, C.c_int, C.c_int]
     L.crsdr_covariance.argtypes = [f32p, i8p, C.c_int, C.c_int, C.c_int]
+    L.crsdr_noisesubspace.argtypes = [f32p, f32p, f32p, C.c_int, C.c_int]
+    L.crsdr_pmusic2d.argtypes = [f32p, f32p, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
     L.crsdr_plan_create.argtypes = [C.POINTER(vp), C.POINTER(PlanDesc)]
     L.crsdr_plan_destroy.argtypes = [vp]
     L.crsdr_plan_reset.argtypes = [vp]
@@ -205,6 +208,29 @@ def covariance_device(rxx_ptr: int, matrix_ptr: int, nrows: int, B: int):
     """Same on device memory (both pointers on the current device); returns after the kernels finished."""
     _check(lib().crsdr_covariance(C.cast(C.c_void_p(int(rxx_ptr)), C.POINTER(C.c_float)),
                                   C.cast(C.c_void_p(int(matrix_ptr)), C.POINTER(C.c_int8)), nrows, B, MEM_DEVICE))
+
+
+def noisesubspace(rxx):
+    """noisesubspace(Rxx, K) of beamformclient/heatmap2d2.cpp:69-79 without the column cut: returns (vec, sv) with
+    vec[:, r] the singular vector of sv[r], sv descending; the noise subspace for K sources is vec[:, K:]."""
+    r = np.ascontiguousarray(rxx, dtype=np.complex64)
+    if r.ndim != 2 or r.shape[0] != r.shape[1]:
+        raise ValueError("rxx must be square")
+    M = r.shape[0]
+    vec = np.empty((M, M), dtype=np.complex64)
+    sv = np.empty(M, dtype=np.float32)
+    _check(lib().crsdr_noisesubspace(_p(vec.view(np.float32), C.c_float), _p(sv, C.c_float), _p(r.view(np.float32), C.c_float), M, MEM_HOST))
+    return vec, sv
+
+
+def pmusic2d(vec, k, d, mx, my, ncx=100, ncy=100):
+    """pmusic2dvec(Un, d, Mx, My, Cx, Cy) of beamformclient/heatmap2d2.cpp:137-147 with Un = vec[:, k:]."""
+    v = np.ascontiguousarray(vec, dtype=np.complex64)
+    M = v.shape[0]
+    pm = np.empty((max(ncx, 0), max(ncy, 0)), dtype=np.float32)
+    _check(lib().crsdr_pmusic2d(_p(pm, C.c_float), _p(v.view(np.float32), C.c_float), M, int(k), C.c_float(d), int(mx), int(my),
+                                int(ncx), int(ncy), MEM_HOST))
+    return pm
 
 
 # ---- batched plan ---------------------------------------------------------------------------------

@@ -421,6 +421,68 @@ extern "C" int crsdr_covariance(float *rxx, const int8_t *matrix, int nrows, int
     return CRSDR_OK;
 }
 
+extern "C" int crsdr_noisesubspace(float *vec, float *sv, const float *rxx, int m, int mem_kind)
+{
+    if (!vec || !rxx || m < 2 || m > music::MAX_M) return fail(CRSDR_EINVAL, "noisesubspace: need vec, rxx, 2 <= m <= %d", music::MAX_M);
+    if (mem_kind != CRSDR_MEM_HOST && mem_kind != CRSDR_MEM_DEVICE) return fail(CRSDR_EINVAL, "noisesubspace: mem_kind = %d", mem_kind);
+    { int rc_ = require_device(); if (rc_) return rc_; }
+    std::lock_guard<std::mutex> lock_(g_op.mu);
+    const size_t mm = sizeof(float2) * (size_t)m * m;
+    OP_RESERVE(2, music::MAX_M * sizeof(float) + 2 * sizeof(int));
+    float *d_sv = (float *)g_op.buf[2];
+    int *d_info = (int *)((char *)g_op.buf[2] + music::MAX_M * sizeof(float));
+    const float2 *d_r = (const float2 *)rxx;
+    float2 *d_v = (float2 *)vec;
+    if (mem_kind == CRSDR_MEM_HOST) {
+        OP_RESERVE(0, mm); OP_RESERVE(1, mm);
+        HIP_TRY(hipMemcpy(g_op.buf[0], rxx, mm, hipMemcpyHostToDevice));
+        d_r = (const float2 *)g_op.buf[0];
+        d_v = (float2 *)g_op.buf[1];
+    }
+    const size_t lds = 2 * sizeof(double2) * (size_t)m * m;
+    HIP_TRY(hipFuncSetAttribute((const void *)music::k_herm_subspace, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(music::k_herm_subspace, dim3(1), dim3(music::JT), lds, 0, d_r, m, d_sv, d_v, d_info);
+    HIP_TRY(hipGetLastError());
+    int info[2] = {0, 0};
+    HIP_TRY(hipMemcpy(info, d_info, sizeof(info), hipMemcpyDeviceToHost));
+    if (mem_kind == CRSDR_MEM_HOST) {
+        HIP_TRY(hipMemcpy(vec, d_v, mm, hipMemcpyDeviceToHost));
+        if (sv) HIP_TRY(hipMemcpy(sv, d_sv, sizeof(float) * (size_t)m, hipMemcpyDeviceToHost));
+    } else if (sv) {
+        HIP_TRY(hipMemcpy(sv, d_sv, sizeof(float) * (size_t)m, hipMemcpyDeviceToDevice));
+    }
+    if (!info[1]) return fail(CRSDR_ESTATE, "noisesubspace: Jacobi iteration not converged after %d sweeps", info[0]);
+    return CRSDR_OK;
+}
+
+extern "C" int crsdr_pmusic2d(float *pm, const float *vec, int m, int k, float d, int mx, int my, int ncx, int ncy, int mem_kind)
+{
+    if (!pm || !vec || m < 2 || m > music::MAX_M || mx < 1 || my < 1 || mx * my != m || k < 1 || k >= m || ncx < 1 || ncy < 1 ||
+        (long long)ncx * ncy > (1 << 24))
+        return fail(CRSDR_EINVAL, "pmusic2d: need pm, vec, m = mx*my in [2, %d], 1 <= k < m, grid <= 2^24 points", music::MAX_M);
+    if (mem_kind != CRSDR_MEM_HOST && mem_kind != CRSDR_MEM_DEVICE) return fail(CRSDR_EINVAL, "pmusic2d: mem_kind = %d", mem_kind);
+    { int rc_ = require_device(); if (rc_) return rc_; }
+    std::lock_guard<std::mutex> lock_(g_op.mu);
+    const size_t mm = sizeof(float2) * (size_t)m * m, pb = sizeof(float) * (size_t)ncx * ncy;
+    const float2 *d_v = (const float2 *)vec;
+    float *d_p = pm;
+    if (mem_kind == CRSDR_MEM_HOST) {
+        OP_RESERVE(0, mm); OP_RESERVE(1, pb);
+        HIP_TRY(hipMemcpy(g_op.buf[0], vec, mm, hipMemcpyHostToDevice));
+        d_v = (const float2 *)g_op.buf[0];
+        d_p = (float *)g_op.buf[1];
+    }
+    const int nn = m - k;
+    const size_t lds = sizeof(float2) * ((size_t)m * nn + (size_t)m * music::PT);
+    HIP_TRY(hipFuncSetAttribute((const void *)music::k_pmusic2d, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const unsigned blocks = (unsigned)(((size_t)ncx * ncy + music::PT - 1) / music::PT);
+    hipLaunchKernelGGL(music::k_pmusic2d, dim3(blocks), dim3(music::PT), lds, 0, d_v, m, m, k, nn, d, mx, my, ncx, ncy, d_p);
+    HIP_TRY(hipGetLastError());
+    if (mem_kind == CRSDR_MEM_HOST) HIP_TRY(hipMemcpy(pm, d_p, pb, hipMemcpyDeviceToHost));
+    else HIP_TRY(hipDeviceSynchronize());
+    return CRSDR_OK;
+}
+
 // ================================================================================================
 // (ii) batched plan
 // ================================================================================================
@@ -452,6 +514,7 @@ struct crsdr_plan {
     int log2n1 = 0;
     float2 *d_wc = nullptr, *d_wf = nullptr, *d_tw1 = nullptr, *d_Y = nullptr, *d_Yref = nullptr;
     lb::LongPartial *d_part = nullptr;
+    int long_chunk = 1 << 30; // rows per pass of the long-block stages
     // pinned staging ring for the small per-batch host arrays
     uint32_t *h_readcnt = nullptr;
     uint8_t *h_mask = nullptr;
@@ -517,6 +580,11 @@ static int plan_alloc(crsdr_plan *p)
         if ((rc = make_twiddle_table((double)n1, n1, 1, &p->d_tw1))) return rc;
         HIP_TRY(hipMalloc((void **)&p->d_Y, sizeof(float2) * Bz * (size_t)p->row_count));
         HIP_TRY(hipMalloc((void **)&p->d_Yref, sizeof(float2) * Bz));
+        {
+            const char *e = getenv("CRSDR_LONG_CHUNK_MB");
+            const long mb = e ? atol(e) : 200; // measured on cfg5 (21 x 2^21): 64 MB -4 %, 128 MB +1.5 %, 200 MB +4.7 %, unchunked 0
+            if (mb > 0) p->long_chunk = (int)std::max<size_t>(1, ((size_t)mb << 20) / (sizeof(float2) * Bz));
+        }
         HIP_TRY(hipMalloc((void **)&p->d_part, sizeof(lb::LongPartial) * (size_t)lb::ntiles(p->log2n1) * (size_t)p->row_count));
     }
     const size_t n = (size_t)p->nrows, T = (size_t)p->max_batch;
@@ -752,9 +820,14 @@ extern "C" int crsdr_plan_submit_batch(crsdr_plan *p, const void *rows, int mem_
         xa.lag_state = p->d_lag_state; xa.mag_state = p->d_mag_state; xa.frac_state = p->d_frac_state;
         hipEvent_t *pe1 = prof_pair(p, CRSDR_KERNEL_XCORR_LAG);
         if (pe1) HIP_TRY(hipEventRecord(pe1[0], S));
-        HIP_TRY(CRSDR_DISPATCH_N1(l1, (launch_long_fwd_cols<LG, false>(S, p->row_count, d_in, p->row_begin, xor80, tw, p->d_Y))));
-        HIP_TRY(launch_long_rows<false>(S, n1, p->row_count, p->d_Y, p->d_twA, p->d_twB, p->d_refspec[0]));
-        HIP_TRY(CRSDR_DISPATCH_N1(l1, (launch_long_inv_cols<LG>(S, p->row_count, p->d_Y, tw, p->d_part))));
+        // rows go through the three stages in chunks whose cf32 work area fits the 256 MB memory-side cache
+        for (int r0 = 0; r0 < p->row_count; r0 += p->long_chunk) {
+            const int cnt = std::min(p->long_chunk, p->row_count - r0);
+            float2 *Yc = p->d_Y + (size_t)r0 * (size_t)p->B;
+            HIP_TRY(CRSDR_DISPATCH_N1(l1, (launch_long_fwd_cols<LG, false>(S, cnt, d_in, p->row_begin + r0, xor80, tw, Yc))));
+            HIP_TRY(launch_long_rows<false>(S, n1, cnt, Yc, p->d_twA, p->d_twB, p->d_refspec[0]));
+            HIP_TRY(CRSDR_DISPATCH_N1(l1, (launch_long_inv_cols<LG>(S, cnt, Yc, tw, p->d_part + (size_t)r0 * lb::ntiles(l1)))));
+        }
         hipLaunchKernelGGL(lb::k_long_finalize, dim3(p->row_count), dim3(256), 0, S, p->d_Y, p->d_part, tw, n1, lb::ntiles(l1), xa);
         HIP_TRY(hipGetLastError());
         if (pe1) HIP_TRY(hipEventRecord(pe1[1], S));

@@ -24,6 +24,7 @@
 #include "xcorr14.hpp"
 #include "longblock.hpp"
 #include "covariance.hpp"
+#include "music.hpp"
 #include <stdint.h>
 
 namespace crsdr {

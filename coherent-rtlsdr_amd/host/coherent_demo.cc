@@ -10,6 +10,7 @@
 #include <string>
 #include <unistd.h>
 
+#include "cbeamformer.h"
 #include "ccoherent.h"
 #include "ccontrol.h"
 
@@ -49,7 +50,7 @@ int main(int argc, char **argv)
 {
     int nsig = 3, L = 8192, blocks = 12, mode = CRSDR_MODE_DIGITAL, dmax = -1;
     std::string dump, zmqaddr;
-    bool run_cdsp = false, servo = false, threads = false;
+    bool run_cdsp = false, servo = false, threads = false, music = false;
     int pace_ms = 0;
     for (int i = 1; i < argc; ++i) {
         std::string a = argv[i];
@@ -66,6 +67,7 @@ int main(int argc, char **argv)
         else if (a == "--zmq" && i + 1 < argc) zmqaddr = argv[++i];           // e.g. tcp://127.0.0.1:5555 (reference: tcp://*:5555)
         else if (a == "--zmq-debug" && i + 1 < argc) cpacketize::debugaddress = argv[++i];
         else if (a == "--pace-ms") val(pace_ms);
+        else if (a == "--music") music = true;      // f4: the last packet through the beamformer chain (needs nsig = 7 x 3)
     }
     int fails = 0;
     if (run_cdsp) fails += cdsp_selftest();
@@ -80,9 +82,11 @@ int main(int argc, char **argv)
     cpacketize::init(zmqaddr, false, 1 + nsig, B);             // src/main.cc:261 binds tcp://*:5555
     if (!zmqaddr.empty()) { std::printf("zmq publish on %s: %s\n", zmqaddr.c_str(), cpacketize::publishing() ? "bound" : "unavailable"); usleep(300 * 1000); }
     size_t packets = 0, last_bytes = 0; uint32_t last_seq = 0, last_N = 0, last_L = 0;
+    std::vector<int8_t> last_packet;
     cpacketize::sink = [&](const int8_t *p, size_t bytes, const std::complex<float> *, size_t) {
         const hdr0 *h = reinterpret_cast<const hdr0 *>(p);
         last_seq = h->globalseqn; last_N = h->N; last_L = h->L; last_bytes = bytes; ++packets;
+        if (music) last_packet.assign(p, p + bytes);
     };
     ccoherent coherent(&ref, &devs, &refnoise, 8, mode);
 
@@ -170,6 +174,26 @@ int main(int argc, char **argv)
         std::printf("row %d: lag %6.0f (injected %6ld) mag %10.1f  phasor %+.4f%+.4fj  residual phase %+.5f rad  %s\n", 1 + k,
                     lp->lag, (long)p->d[k], lp->mag, ph.real(), ph.imag(), resid, (lag_ok && ph_ok) ? "ok" : "MISMATCH");
         fails += !(lag_ok && ph_ok);
+    }
+    if (music) {
+        // what the reference's beamformer client does with a packet (beamformclient/heatmap2d2.cpp:185-203).  The
+        // synthetic channels all carry the reference noise, so once aligned the array sees one source at
+        // broadside: steering vector of all ones, alpha = beta = pi/2, grid point (50, 50).
+        cmatrix Rxx, U;
+        std::vector<float> S, pm;
+        int M = 0;
+        if (nsig != cbeamformer::MX * cbeamformer::MY || cbeamformer::covariance(last_packet.data(), Rxx, M) ||
+            cbeamformer::noisesubspace(Rxx, M, U, &S) ||
+            cbeamformer::pmusic2dvec(U, M, 1, cbeamformer::D, cbeamformer::MX, cbeamformer::MY, cbeamformer::CX, cbeamformer::CY, pm)) {
+            std::printf("music: chain failed (needs --nsig 21)\n");
+            ++fails;
+        } else {
+            size_t best = 0;
+            for (size_t i = 1; i < pm.size(); ++i) if (pm[i] > pm[best]) best = i;
+            const int cx = (int)(best / cbeamformer::CY), cy = (int)(best % cbeamformer::CY);
+            std::printf("music: singular values %.4f %.4f .. %.4f, peak (%d, %d) of %d x %d\n", S[0], S[1], S[M - 1], cx, cy, cbeamformer::CX, cbeamformer::CY);
+            fails += (mode == CRSDR_MODE_DIGITAL) && !(cx == 50 && cy == 50 && S[0] > 10 * S[1]);
+        }
     }
     std::printf("packets sent %zu, last hdr {seq %u, N %u, L %u}, %zu bytes\n", packets, last_seq, last_N, last_L, last_bytes);
     fails += (packets != (size_t)blocks) + (last_N != (uint32_t)(1 + nsig)) + (last_L != (uint32_t)L) + (last_seq != (uint32_t)(blocks - 1));

@@ -236,6 +236,25 @@ int crsdr_plan_kernel_times(crsdr_plan *plan, int which, float *ms, int capacity
  * blocksize % 32 == 0.  mem_kind: CRSDR_MEM_HOST (copied) or CRSDR_MEM_DEVICE (both pointers on the device). */
 int crsdr_covariance(float *rxx, const int8_t *matrix, int nrows, int blocksize, int mem_kind);
 
+/* Signal / noise subspaces of a Hermitian covariance, replacing noisesubspace(Rxx, K)
+ * (beamformclient/heatmap2d2.cpp:69-79: BDCSVD of Rxx, Un = U.rightCols(M - K)).
+ *   rxx [m][m][2] float row-major (the output of crsdr_covariance), 2 <= m <= 64
+ *   sv  [m] singular values, descending (NULL to skip)
+ *   vec [m][m][2] float row-major; column r is the singular vector of sv[r], so the noise subspace for K
+ *       sources is columns K .. m-1 (a basis of it: only the projector Un Un^H is unique)
+ * One workgroup, one-sided Jacobi in fp64 with the matrix resident in LDS; no host arithmetic.
+ * Returns CRSDR_ESTATE if the iteration did not converge (vec / sv are still written). */
+int crsdr_noisesubspace(float *vec, float *sv, const float *rxx, int m, int mem_kind);
+
+/* 2-D MUSIC pseudo-spectrum of a uniform rectangular array, replacing pmusic2dvec(Un, d, Mx, My, Cx, Cy)
+ * with s_vecd2d and pmusic (beamformclient/heatmap2d2.cpp:103-147, called at :199 with d = 1.225*1.24/3,
+ * Mx = 7, My = 3, Cx = Cy = 100):
+ *   a(alpha, beta)[iy*mx + ix] = exp(2 pi j ix d cos(alpha) sin(beta)) exp(2 pi j iy d cos(beta)),
+ *   alpha = cx pi / ncx, beta = cy pi / ncy,   pm[cx][cy] = ( |a|^2 / |Un^H a|^2 )^2      (squared twice, :123)
+ *   vec [m][m][2] as written by crsdr_noisesubspace, m = mx*my <= 64; Un = its columns k .. m-1, 1 <= k < m
+ *   pm  [ncx][ncy] float row-major, not normalised (the reference divides by the maximum for plotting, :202-203) */
+int crsdr_pmusic2d(float *pm, const float *vec, int m, int k, float d, int mx, int my, int ncx, int ncy, int mem_kind);
+
 #ifdef __cplusplus
 }
 #endif

@@ -99,6 +99,11 @@ int orc_engine_block_mt(orc_engine *e, const int8_t *rows, const uint32_t *readc
                         int32_t *lag, float *mag, float *frac, float *phasor, int8_t *packet,
                         int nthreads);
 
+/* ---- beamformer_oracle.c: the first consumer of the matrix (beamformclient/heatmap2d2.cpp) ---- */
+void orc_covariance(float *rxx, const int8_t *matrix, int nrows, int B);                   /* :185-199 */
+int orc_noisesubspace(float *vec, float *sv, const float *rxx, int M);                     /* :69-79   */
+void orc_pmusic2d(float *pm, const float *vec, int M, int k, float d, int Mx, int My, int Cx, int Cy); /* :103-147 */
+
 #ifdef __cplusplus
 }
 #endif

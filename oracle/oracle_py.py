@@ -18,7 +18,7 @@ FAITHFUL, DIGITAL = 0, 1
 
 
 def build(force: bool = False) -> str:
-    src = [os.path.join(_HERE, f) for f in ("coherent_oracle.c", "coherent_oracle.h", "Makefile")]
+    src = [os.path.join(_HERE, f) for f in ("coherent_oracle.c", "beamformer_oracle.c", "coherent_oracle.h", "Makefile")]
     stale = force or not os.path.exists(_SO) or any(os.path.getmtime(s) > os.path.getmtime(_SO) for s in src)
     if stale:
         subprocess.run(["make", "-C", _HERE], check=True, stdout=subprocess.DEVNULL)
@@ -56,6 +56,9 @@ def lib():
         L.orc_packet_bytes.restype = C.c_size_t
         L.orc_packet_matrix_offset.argtypes = [C.c_int]
         L.orc_packet_matrix_offset.restype = C.c_size_t
+        L.orc_covariance.argtypes = [f32p, i8p, C.c_int, C.c_int]
+        L.orc_noisesubspace.argtypes = [f32p, f32p, f32p, C.c_int]
+        L.orc_pmusic2d.argtypes = [f32p, f32p, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int, C.c_int, C.c_int]
         _lib = L
     return _lib
 
@@ -138,6 +141,36 @@ def fft(x, sign=-1):
     if rc:
         raise ValueError("orc_fft: bad arguments")
     return out
+
+
+def covariance(matrix):
+    """beamformclient/heatmap2d2.cpp:185-199 on an int8 [nrows][B] matrix -> complex64 [nrows-1][nrows-1]."""
+    m = np.ascontiguousarray(matrix, dtype=np.int8)
+    nrows, B = m.shape
+    out = np.empty((nrows - 1, nrows - 1), dtype=np.complex64)
+    lib().orc_covariance(_p(out, C.c_float), _p(m, C.c_int8), nrows, B)
+    return out
+
+
+def noisesubspace(rxx):
+    """heatmap2d2.cpp:69-79: (vec, sv); vec[:, r] is the singular vector of sv[r] (descending)."""
+    r = np.ascontiguousarray(rxx, dtype=np.complex64)
+    M = r.shape[0]
+    vec = np.empty((M, M), dtype=np.complex64)
+    sv = np.empty(M, dtype=np.float32)
+    rc = lib().orc_noisesubspace(_p(vec, C.c_float), _p(sv, C.c_float), _p(r, C.c_float), M)
+    if rc < 0:
+        raise RuntimeError("oracle Jacobi iteration did not converge")
+    return vec, sv
+
+
+def pmusic2d(vec, k, d, mx, my, ncx, ncy):
+    """heatmap2d2.cpp:103-147 pseudo-spectrum [ncx][ncy] (not normalised)."""
+    v = np.ascontiguousarray(vec, dtype=np.complex64)
+    M = v.shape[0]
+    pm = np.empty((ncx, ncy), dtype=np.float32)
+    lib().orc_pmusic2d(_p(pm, C.c_float), _p(v, C.c_float), M, k, d, mx, my, ncx, ncy)
+    return pm
 
 
 class Engine:

@@ -317,3 +317,83 @@ def test_maximum_block_size_plan(b, synth):
         b.Plan(2, 1 << 23)                                        # beyond the supported range
     with pytest.raises(b.CrsdrError):
         b.Plan(2, 1 << 21, max_batch=2)                           # long blocks are submitted one at a time
+
+
+def _delayed_rows(L, delays, phis, seed=5, sigma=30.0):
+    """ref row = seeded complex Gaussian; row k = ref delayed by delays[k] samples and rotated by phis[k]
+    (noise-free), the construction of the oracle's known-answer tests (tests/test_oracle_engine.py)."""
+    rng = np.random.default_rng(seed)
+    pad = L
+    r_ext = rng.standard_normal(L + 2 * pad) + 1j * rng.standard_normal(L + 2 * pad)
+    rows = np.zeros((1 + len(delays), 2 * L), dtype=np.int8)
+
+    def q(x):
+        out = np.empty(2 * L, dtype=np.int8)
+        out[0::2] = np.clip(np.rint(x.real), -128, 127)
+        out[1::2] = np.clip(np.rint(x.imag), -128, 127)
+        return out
+
+    n = np.arange(L)
+    rows[0] = q(sigma * r_ext[pad:pad + L])
+    for k, (d, phi) in enumerate(zip(delays, phis)):
+        rows[1 + k] = q(sigma * r_ext[n - d + pad] * np.exp(1j * phi))
+    return rows
+
+
+@pytest.mark.parametrize("L", [4096, 8192, 1 << 15])
+def test_known_delays_give_idx_L_plus_d(b, L):
+    # SURVEY 8c known answers, on the HIP path at the reference block size and either side of it:
+    # s[n] = r[n - d]  ->  idx = L + d, lag = +d, for d in {0, +-1, +-7, +-1000, -L/2+1, L/2-1}
+    delays = [0, 1, -1, 7, -7, 1000, -1000, -L // 2 + 1, L // 2 - 1]
+    rows = _delayed_rows(L, delays, [0.0] * len(delays))
+    for mode in (b.MODE_FAITHFUL, b.MODE_DIGITAL):
+        plan = b.Plan(1 + len(delays), 2 * L, mode)
+        out = plan.block(rows)
+        assert list(out["lag"][1:]) == delays
+        assert np.all(np.abs(out["frac"][1:]) < 0.05)
+        # noise-free integer copy: the peak is B x the overlap energy (src/ccoherent.cc:204)
+        r = rows[0].astype(np.float64) / 127.0
+        e = r[0::2] ** 2 + r[1::2] ** 2
+        for k, d in enumerate(delays):
+            ov = e[:L - d].sum() if d >= 0 else e[-d:].sum()
+            expect = 2 * L * ov / np.sqrt(L)      # unnormalised backward FFT: m[idx] = (B ov)^2, mag = sqrt(m / L)
+            assert abs(out["mag"][1 + k] - expect) <= 1e-4 * expect
+        plan.close()
+
+
+def test_pure_rotation_gives_conjugate_phasor_and_ema(b):
+    # a10: corr = sum s conj(r) = |.| e^{j phi}; p_raw = e^{-j phi}; EMA from p_prev = 1 (src/csdrdevice.cc:39-40,63-67)
+    L = 8192
+    phis = [0.3, -1.2, 2.9, -3.0]
+    rows = _delayed_rows(L, [0] * 4, phis)
+    plan = b.Plan(5, 2 * L, b.MODE_FAITHFUL)
+    out = plan.block(rows)
+    for k, phi in enumerate(phis):
+        assert abs(out["phasor"][1 + k] - (0.5 * np.exp(-1j * phi) + 0.5)) < 2e-3
+    for t in range(20):
+        out = plan.block(rows, seq=1 + t)
+    for k, phi in enumerate(phis):
+        assert abs(out["phasor"][1 + k] - np.exp(-1j * phi)) < 2e-3
+    frozen = out["phasor"].copy()
+    out = plan.block(_delayed_rows(L, [0] * 4, [1.0] * 4), seq=30, flags=0)          # refnoise off: estimate frozen
+    assert np.array_equal(out["phasor"], frozen)
+    plan.close()
+
+
+def test_digital_mode_centres_the_correlation_peak(b, model):
+    # mirrors matlabclient/seqnum_and_correlation.m:27-43 on the HIP path: after alignment every row of the
+    # published matrix correlates with the ref row at the centre (lag 0) with the phase removed
+    L = 8192
+    delays, phis = [13, -200, 511, -2047], [0.7, -2.0, 3.0, 0.1]
+    rows = _delayed_rows(L, delays, phis)
+    plan = b.Plan(5, 2 * L, b.MODE_DIGITAL)
+    for t in range(12):
+        out = plan.block(rows, seq=t)
+    ref = model.to_complex(out["matrix"][0])
+    for k in range(4):
+        y = model.to_complex(out["matrix"][1 + k])
+        lag, _, _, _ = model.xcorr_lag(y, ref)
+        assert lag == 0
+        assert abs(np.angle(np.sum(y * np.conj(ref)))) < 2e-2
+    plan.close()
+

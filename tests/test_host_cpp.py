@@ -64,6 +64,17 @@ def test_host_demo_on_gpu(host_build, args, tmp_path, synth):
 
 
 @pytest.mark.gpu
+def test_host_demo_beamformer_chain_sees_the_aligned_noise_at_broadside(host_build):
+    # SURVEY 8 f4 through the host mirror of the beamformer client (cbeamformer.h): 21 aligned channels of the
+    # reference noise are one source with an all-ones steering vector -> MUSIC peak at alpha = beta = pi/2
+    r = subprocess.run([os.path.join(host_build, "coherent_demo"), "--nsig", "21", "--blocks", "12", "--music"],
+                       capture_output=True, text=True, timeout=300)
+    print(r.stdout, r.stderr)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "peak (50, 50) of 100 x 100" in r.stdout and "DEMO OK" in r.stdout
+
+
+@pytest.mark.gpu
 def test_servo_model_drives_track_to_locked(host_build):
     # ccontrol's loop (descent = 2^-11 tanh(lag/100), hold 0.9 |lag/(p fs)|, sync_threshold) over
     # the modelled resampler: every row ends synchronized with zero residual delay, the engine then runs its
