@@ -42,7 +42,7 @@ def parse():
     ap.add_argument("--L", type=int, default=8192, help="complex samples per row per block")
     ap.add_argument("--nbuf", type=int, default=32, help="distinct resident input blocks rotated through")
     ap.add_argument("--batch", type=int, default=0, help="consecutive blocks per submit (one launch set per batch); "
-                    "0 = 16 on one GPU, 32 on several: with the rows sharded a rank's batch shrinks, so it carries more blocks")
+                    "0 = 16 on one GPU, 32 on two, 64 on more: with the rows sharded a rank's batch shrinks, so it carries more blocks")
     ap.add_argument("--mode", choices=["digital", "faithful"], default="digital")
     ap.add_argument("--cfg5", action="store_true", help="BASELINE config 5 instead: 1 + 21 rows x 2^20 samples (long-block path)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -91,7 +91,9 @@ def main():
     mode = b.MODE_DIGITAL if args.mode == "digital" else b.MODE_FAITHFUL
 
     # ---- synthetic resident input: nbuf distinct blocks, each rank fills row 0 + its slab ----------
-    T = max(1, min(args.batch if args.batch > 0 else (16 if world == 1 else 32), args.steps, 64))
+    T = max(1, min(args.batch if args.batch > 0 else {1: 16, 2: 32}.get(world, 64), args.steps, 64))
+    if world > 1:
+        T = max(world, T // world * world)          # every rank assembles T/G blocks of each batch
     nbuf = max(2 * T if world > 1 else T, (args.nbuf // T) * T)   # whole batches, contiguous in HBM
     seed = synth.config_seed(4)
     params = synth.RowParams(nsig, L, seed)
@@ -105,40 +107,54 @@ def main():
     plan = b.Plan(nrows, B, mode, device=local_rank, row_begin=slab.row_begin, row_count=slab.row_count, max_batch=T)
     stream = torch.cuda.current_stream()
     plan.set_stream(stream.cuda_stream)
-    # NSETS sets of T packets (ring-buffered against the exchange in flight); matrix of every packet 16-byte aligned
-    NSETS = 4 if world > 1 else 2
+    # NSETS ring-buffered output sets (the exchange of batch i runs under the compute of batch i+1); the matrix
+    # of every packet is 16-byte aligned.  One GPU: T packets per set.  Several GPUs: per set one dense slab
+    # buffer [T][rows_per_rank][B] (the all-to-all's send side), one receive buffer of the same size and the
+    # Tg = T/G packets this rank assembles.
+    NSETS = 3 if world > 1 else 2
+    Tg = T // world
     pstride = (plan.packet_bytes + 255) // 256 * 256
-    packets = [torch.zeros(pstride * T + 64, dtype=torch.uint8, device=dev) for _ in range(NSETS)]
+    packets = [torch.zeros(pstride * Tg + 64, dtype=torch.uint8, device=dev) for _ in range(NSETS)]
     pk_off = [(-(p.data_ptr() + plan.matrix_offset)) % 16 for p in packets]
-    pk_view = [[p[o + t * pstride: o + t * pstride + plan.packet_bytes] for t in range(T)] for p, o in zip(packets, pk_off)]
+    pk_view = [[p[o + t * pstride: o + t * pstride + plan.packet_bytes] for t in range(Tg)] for p, o in zip(packets, pk_off)]
     flags = b.REFNOISE_ENABLED | b.INPUT_READY
-    works = [[] for _ in range(NSETS)]
+    slab_bytes = slab.row_count * B
+    if world > 1:
+        send = [torch.zeros(T * slab_bytes, dtype=torch.uint8, device=dev) for _ in range(NSETS)]
+        recv = [torch.zeros(T * slab_bytes, dtype=torch.uint8, device=dev) for _ in range(NSETS)]
+        xstream = torch.cuda.Stream(device=dev)       # waits for the exchange, then assembles: never blocks the compute stream
+        done = [None] * NSETS                          # event: set k's exchange + assembly finished
+        mine = sharding.rooted_blocks(T, world, rank)
 
     def run_batch(ib, nb, fl=flags):
-        """blocks [ib*T, ib*T + nb) of the stream: one submit, then ONE grouped exchange for the batch
-        (block b is assembled on rank b mod G: every link carries one slab per block, no hot root)"""
+        """blocks [ib*T, ib*T + nb) of the stream: one submit; with several GPUs then ONE all-to-all of the batch's
+        slabs (rank q assembles blocks [q*T/G, (q+1)*T/G) of every batch) and the assembly on a side stream"""
         k = ib % NSETS
-        for w in works[k]:
-            w.wait()                 # stream-level: the exchange that read this packet set is done
-        works[k] = []
-        plan.bind_packet(pk_view[k][0].data_ptr(), pstride)
         first_buf = (ib * T) % nbuf
+        if world == 1:
+            plan.bind_packet(pk_view[k][0].data_ptr(), pstride)
+            plan.submit(d_in[first_buf].data_ptr(), seq=ib * T, flags=fl, nblocks=nb, block_stride=block_bytes)
+            return
+        if done[k] is not None:
+            stream.wait_event(done[k])               # set k is free again: its exchange and assembly are complete
+        plan.bind_packet(pk_view[k][0].data_ptr(), pstride)
+        plan.bind_slab(send[k].data_ptr(), slab_bytes, mine.start, len(mine))
         plan.submit(d_in[first_buf].data_ptr(), seq=ib * T, flags=fl, nblocks=nb, block_stride=block_bytes)
-        if world > 1 and not rehearsal:
-            works[k] = list(sharding.gather_batch(pk_view[k][:nb], nrows, B, slab, ib * T))
-        elif world > 1:
+        if rehearsal:
             plan.sync()
-            host = [v.cpu() for v in pk_view[k][:nb]]
-            for w in sharding.gather_batch(host, nrows, B, slab, ib * T):
-                w.wait()
-            for v, h in zip(pk_view[k][:nb], host):
-                v.copy_(h)
+            h_send, h_recv = send[k].cpu(), torch.empty(T * slab_bytes, dtype=torch.uint8)
+            sharding.exchange_batch(h_recv, h_send, async_op=False)
+            recv[k].copy_(h_recv)
+            b.assemble_slabs(pk_view[k][0].data_ptr(), pstride, nrows, B, recv[k].data_ptr(), world, Tg, stream.cuda_stream)
+            return
+        work = sharding.exchange_batch(recv[k], send[k], async_op=True)     # RCCL stream: ordered after the submit above
+        with torch.cuda.stream(xstream):
+            work.wait()                              # stream-level: xstream waits for the all-to-all
+            b.assemble_slabs(pk_view[k][0].data_ptr(), pstride, nrows, B, recv[k].data_ptr(), world, Tg, xstream.cuda_stream)
+            done[k] = torch.cuda.Event()
+            done[k].record(xstream)
 
     def fence():
-        for k in range(NSETS):
-            for w in works[k]:
-                w.wait()
-            works[k] = []
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
@@ -164,12 +180,11 @@ def main():
             dt = float(t.item())
         return dt
 
-    # communicator set-up (not a step): RCCL opens its point-to-point channels lazily, on the first send/recv
-    # of each rank pair -- do that here, with the exchange pattern of one full batch on a still-empty packet
-    # set, so that a warm-up shorter than one batch does not leave connection set-up inside the timed region
+    # communicator set-up (not a step): RCCL opens its point-to-point channels lazily, on the first exchange
+    # between each rank pair -- do that here, on the still-empty buffers, so that connection set-up cannot land
+    # inside the timed region whatever the warm-up length is
     if world > 1 and not rehearsal:
-        for w in sharding.gather_batch(pk_view[NSETS - 1], nrows, B, slab, 0):
-            w.wait()
+        sharding.exchange_batch(recv[NSETS - 1], send[NSETS - 1], async_op=False)
         torch.cuda.synchronize()
         dist.barrier()
 
@@ -195,19 +210,20 @@ def main():
     own = slice(slab.row_begin, slab.row_begin + slab.row_count)
     lags_ok = bool(np.array_equal(out["lag"][own], params.d[slab.row_begin - 1: slab.row_begin - 1 + slab.row_count]))
 
-    # the last batch's packets: on the rank that roots a block every slab must have arrived (row 0 of
-    # every other rank's slab is non-zero int8 data with overwhelming probability)
+    # the last full batch: every packet this rank assembled must hold a slab from every rank (row 0 of each
+    # slab is non-zero int8 data with overwhelming probability) under the header of the right block
     assembled_ok = True
     if world > 1:
         torch.cuda.synchronize()
         nfull = args.steps // T
         if nfull:
             ib = nfull - 1
-            for t_ in range(T):
-                if sharding.gather_root(ib * T + t_, world) == rank:
-                    m = sharding.matrix_view(pk_view[ib % NSETS][t_], nrows, B)
-                    for r in range(world):
-                        assembled_ok &= bool(m[1 + r * slab.rows_per_rank].ne(0).any().item())
+            for j, t_ in enumerate(mine):
+                pkv = pk_view[ib % NSETS][j]
+                m = sharding.matrix_view(pkv, nrows, B)
+                for r in range(world):
+                    assembled_ok &= bool(m[1 + r * slab.rows_per_rank].ne(0).any().item())
+                assembled_ok &= int(pkv[:4].cpu().numpy().view(np.uint32)[0]) == ib * T + t_
         flag = torch.tensor([1 if assembled_ok else 0], device="cpu" if rehearsal else dev, dtype=torch.int32)
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         assembled_ok = bool(flag.item())
@@ -229,7 +245,7 @@ def main():
                                    f"(FFT xcorr every block), {args.mode} mode, inputs resident in HBM, "
                                    f"{nbuf} rotating input blocks, {T} blocks per submit",
                        "rows": nrows, "L": L, "fft_len": B, "mode": args.mode, "batch": T,
-                       "parallelism": f"rows sharded x{world}, ref replicated, rotating-root int8 gather (one grouped RCCL exchange per batch)" if world > 1 else "single GPU"},
+                       "parallelism": f"rows sharded x{world}, ref replicated, rotating-root int8 gather: one RCCL all-to-all per {T}-block batch + local assembly, overlapped with the next batch" if world > 1 else "single GPU"},
             "roofline": {"bound": "hbm", "kernel": "k_xcorr_lag", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": _committed_traffic("k_xcorr_lag"),
                          "algorithmic_bytes_per_launch": k1_bytes, "avg_launch_ms": k1,

@@ -29,7 +29,7 @@ ABI_SYMBOLS = [
     "crsdr_plan_matrix_offset", "crsdr_plan_device_buffers", "crsdr_plan_bind_packet",
     "crsdr_plan_last_elapsed_ms", "crsdr_plan_enable_profiling", "crsdr_plan_kernel_times",
     "crsdr_plan_submit_batch", "crsdr_plan_fetch_block", "crsdr_plan_packet_stride", "crsdr_covariance",
-    "crsdr_noisesubspace", "crsdr_pmusic2d",
+    "crsdr_noisesubspace", "crsdr_pmusic2d", "crsdr_plan_bind_slab", "crsdr_assemble_slabs",
 ]
 KERNEL_REF_SPECTRUM, KERNEL_XCORR_LAG, KERNEL_PHASE_DOT, KERNEL_ALIGN_QUANT = 0, 1, 2, 3
 
@@ -64,6 +64,13 @@ def lib():
         return _lib
     if not os.path.exists(_SO):
         raise FileNotFoundError(f"{_SO} is missing: run __graft_entry__.build() (hipcc) first; there is no CPU fallback")
+    # A Python process that also uses PyTorch must load torch's bundled HIP runtime BEFORE this library: both
+    # carry the soname libamdhip64.so.7, the first one loaded serves both, and torch's device init fails on the
+    # system runtime.  (C / C++ hosts are not affected: they link one runtime.)
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = C.CDLL(_SO)
     f32p, i8p, u8p, u32p, i32p, vp = (C.POINTER(C.c_float), C.POINTER(C.c_int8), C.POINTER(C.c_uint8),
                                       C.POINTER(C.c_uint32), C.POINTER(C.c_int32), C.c_void_p)
@@ -95,6 +102,8 @@ def lib():
     L.crsdr_plan_matrix_offset.restype = C.c_size_t
     L.crsdr_plan_device_buffers.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]
     L.crsdr_plan_bind_packet.argtypes = [vp, vp, C.c_size_t]
+    L.crsdr_plan_bind_slab.argtypes = [vp, vp, C.c_size_t, C.c_int, C.c_int]
+    L.crsdr_assemble_slabs.argtypes = [vp, C.c_size_t, C.c_int, C.c_int, vp, C.c_int, C.c_int, vp]
     L.crsdr_plan_submit_batch.argtypes = [vp, vp, C.c_int, C.c_int, C.c_size_t, u32p, u8p, C.c_uint32, C.c_uint32]
     L.crsdr_plan_fetch_block.argtypes = [vp, C.c_int, i32p, f32p, f32p, f32p, i8p]
     L.crsdr_plan_packet_stride.argtypes = [vp]
@@ -233,6 +242,12 @@ def pmusic2d(vec, k, d, mx, my, ncx=100, ncy=100):
     return pm
 
 
+def assemble_slabs(packets_ptr: int, packet_stride: int, nrows: int, B: int, recv_ptr: int, nsrc: int, nblocks: int, stream: int | None = None):
+    """crsdr_assemble_slabs: the received slabs [nsrc][nblocks][per][B] into the matrix rows of nblocks packets (device pointers)."""
+    _check(lib().crsdr_assemble_slabs(C.c_void_p(int(packets_ptr)), int(packet_stride), int(nrows), int(B), C.c_void_p(int(recv_ptr)),
+                                      int(nsrc), int(nblocks), C.c_void_p(stream or 0)))
+
+
 # ---- batched plan ---------------------------------------------------------------------------------
 
 class Plan:
@@ -303,6 +318,10 @@ class Plan:
 
     def bind_packet(self, device_ptr: int | None, packet_stride: int = 0):
         _check(lib().crsdr_plan_bind_packet(self._h, C.c_void_p(device_ptr or 0), int(packet_stride)))
+
+    def bind_slab(self, device_ptr: int | None, slab_stride: int = 0, hdr_first: int = 0, hdr_count: int = 0):
+        """Slab output for sharded plans (crsdr_plan_bind_slab); None returns to packet output."""
+        _check(lib().crsdr_plan_bind_slab(self._h, C.c_void_p(device_ptr or 0), int(slab_stride), int(hdr_first), int(hdr_count)))
 
     @property
     def packet_stride(self) -> int:

@@ -501,6 +501,9 @@ struct crsdr_plan {
     int8_t *d_rows = nullptr;          // staging for host input [T][nrows][B]
     uint8_t *d_packet_alloc = nullptr; // own packet allocation (front padding for alignment)
     int8_t *d_packet_own = nullptr, *d_packet = nullptr;
+    int8_t *d_slab = nullptr;          // slab output mode (crsdr_plan_bind_slab), caller-owned
+    size_t slab_stride = 0;
+    int hdr_first = 0, hdr_count = 0;
     uint32_t *d_readcnt = nullptr;     // [T][nrows]
     uint8_t *d_mask = nullptr;
     int32_t *d_lag = nullptr, *d_lag_state = nullptr;         // [T][nrows], [nrows]
@@ -708,6 +711,38 @@ extern "C" int crsdr_plan_set_stream(crsdr_plan *p, void *hip_stream)
 
 extern "C" size_t crsdr_plan_packet_bytes(const crsdr_plan *p) { return p ? p->packet_bytes : 0; }
 extern "C" size_t crsdr_plan_matrix_offset(const crsdr_plan *p) { return p ? p->matrix_off : 0; }
+extern "C" int crsdr_plan_bind_slab(crsdr_plan *p, void *device_slab, size_t slab_stride, int hdr_first, int hdr_count)
+{
+    if (!p) return fail(CRSDR_EINVAL, "plan_bind_slab: NULL plan");
+    if (!device_slab) { p->d_slab = nullptr; p->slab_stride = 0; p->hdr_first = p->hdr_count = 0; return CRSDR_OK; }
+    if ((uintptr_t)device_slab % 4 || slab_stride % 4 || slab_stride < (size_t)p->row_count * (size_t)p->B || hdr_first < 0 || hdr_count < 0 ||
+        hdr_first + hdr_count > p->max_batch)
+        return fail(CRSDR_EINVAL, "plan_bind_slab: slab and stride 4-byte aligned, stride >= row_count*blocksize, header range inside the batch");
+    p->d_slab = (int8_t *)device_slab; p->slab_stride = slab_stride; p->hdr_first = hdr_first; p->hdr_count = hdr_count;
+    return CRSDR_OK;
+}
+
+extern "C" int crsdr_assemble_slabs(void *device_packets, size_t packet_stride, int nrows, int blocksize, const void *device_recv, int nsrc,
+                                    int nblocks, void *hip_stream)
+{
+    if (!device_packets || !device_recv || nrows < 2 || blocksize < 16 || nsrc < 1 || nblocks < 1 || (nrows - 1) % nsrc)
+        return fail(CRSDR_EINVAL, "assemble_slabs: need packets, recv, nsrc dividing the signal rows, nblocks >= 1");
+    const size_t body_off = 16 + 4 * (size_t)nrows + (size_t)blocksize;          // row 1 of the matrix
+    const size_t slab_bytes = (size_t)((nrows - 1) / nsrc) * (size_t)blocksize;
+    if (((uintptr_t)device_packets + body_off) % 4 || packet_stride % 4 || (uintptr_t)device_recv % 4 ||
+        (nblocks > 1 && packet_stride < body_off + (size_t)(nrows - 1) * blocksize) || nblocks > 65535 || nsrc > 65535)
+        return fail(CRSDR_EINVAL, "assemble_slabs: 4-byte alignment of the matrix rows, stride >= packet bytes");
+    { int rc_ = require_device(); if (rc_) return rc_; }
+    hipStream_t s = (hipStream_t)hip_stream;
+    const bool v16 = (((uintptr_t)device_packets + body_off) % 16 == 0) && (packet_stride % 16 == 0) && ((uintptr_t)device_recv % 16 == 0) && (slab_bytes % 16 == 0);
+    const size_t words = slab_bytes / (v16 ? 16 : 4);
+    const unsigned chunks = (unsigned)std::min<size_t>(std::max<size_t>(1, words / 1024), 64);
+    if (v16) hipLaunchKernelGGL(k_assemble_slabs<uint4>, dim3(chunks, nblocks, nsrc), dim3(256), 0, s, (int8_t *)device_packets, packet_stride, body_off, (const uint4 *)device_recv, nblocks, words);
+    else hipLaunchKernelGGL(k_assemble_slabs<uint32_t>, dim3(chunks, nblocks, nsrc), dim3(256), 0, s, (int8_t *)device_packets, packet_stride, body_off, (const uint32_t *)device_recv, nblocks, words);
+    HIP_TRY(hipGetLastError());
+    return CRSDR_OK;
+}
+
 extern "C" size_t crsdr_plan_packet_stride(const crsdr_plan *p) { return p ? p->packet_stride : 0; }
 
 extern "C" int crsdr_plan_device_buffers(crsdr_plan *p, void **packet, void **lag, void **mag, void **frac, void **phasor)
@@ -803,6 +838,7 @@ extern "C" int crsdr_plan_submit_batch(crsdr_plan *p, const void *rows, int mem_
     aa.digital = (p->mode == CRSDR_MODE_DIGITAL); aa.refnoise = (flags & CRSDR_REFNOISE_ENABLED) ? 1 : 0;
     aa.xcorr_ran = any_lag ? 1 : 0;
     aa.seq = seq; aa.xor80 = xor80;
+    aa.slab = p->d_slab; aa.slab_stride = p->slab_stride; aa.hdr_first = p->hdr_first; aa.hdr_count = p->hdr_count;
 
     if (any_lag && p->longblock) {
         // B = N1 x 16384: column FFTs -> row FFTs (x conj ref, inverse) -> inverse column FFTs + argmax -> finalize
@@ -864,7 +900,8 @@ extern "C" int crsdr_plan_submit_batch(crsdr_plan *p, const void *rows, int mem_
     // 16-byte accesses need 16-byte aligned rows and matrix rows (always true for the plan's own
     // buffers; a caller-bound packet or device input may only be 4-byte aligned -> word kernels)
     const bool vec16 = ((uintptr_t)d_in % 16 == 0) && (d_stride % 16 == 0) && (((uintptr_t)p->d_packet + p->matrix_off) % 16 == 0) &&
-                       (p->packet_stride % 16 == 0 || nblocks == 1);
+                       (p->packet_stride % 16 == 0 || nblocks == 1) &&
+                       (!p->d_slab || ((uintptr_t)p->d_slab % 16 == 0 && p->slab_stride % 16 == 0));
     // phase path: faithful mode does not depend on this batch's lags, digital mode does; either
     // way it follows K1 on the main stream (K1 is VALU bound, these two are the HBM-bound tail)
     const int chunks = p->B > 16384 ? p->B / 16384 : 1; // long rows: 16 KiB of the row per workgroup
@@ -905,6 +942,7 @@ extern "C" int crsdr_plan_fetch_block(crsdr_plan *p, int block, int32_t *lag, fl
     if (!p->submitted) return fail(CRSDR_ESTATE, "plan_fetch: nothing submitted");
     if (block < 0) block = p->last_nblocks - 1;
     if (block >= p->last_nblocks) return fail(CRSDR_EINVAL, "plan_fetch: block %d of a batch of %d", block, p->last_nblocks);
+    if (packet && p->d_slab) return fail(CRSDR_ESTATE, "plan_fetch: slab output is bound, packets are assembled by the caller (crsdr_assemble_slabs)");
     HIP_TRY(hipSetDevice(p->device));
     HIP_TRY(hipStreamSynchronize(p->stream));
     const size_t n = (size_t)p->nrows, o = (size_t)block * n;

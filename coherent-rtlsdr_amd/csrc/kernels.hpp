@@ -310,6 +310,10 @@ __global__ __launch_bounds__(kAlignThreads) void k_align_quant(AlignArgs a)
     const size_t moff = 16 + 4 * (size_t)a.nrows;
     const int8_t *blk = a.rows + (size_t)t * a.block_stride;
     int8_t *packet = a.packet + (size_t)t * a.packet_stride;
+    if (a.slab) {
+        if (blockIdx.x == 0 && (t < a.hdr_first || t >= a.hdr_first + a.hdr_count)) return; // no packet for this block here
+        packet = a.packet + (size_t)(t - a.hdr_first) * a.packet_stride;
+    }
     const int nchunk = gridDim.z, v_lo = (int)(((long long)(B / 16) * blockIdx.z) / nchunk),
               v_hi = (int)(((long long)(B / 16) * (blockIdx.z + 1)) / nchunk);
     if (blockIdx.x == 0) {
@@ -337,6 +341,7 @@ __global__ __launch_bounds__(kAlignThreads) void k_align_quant(AlignArgs a)
     const int row = a.row_begin + (int)blockIdx.x - 1;
     const uint32_t *s32 = reinterpret_cast<const uint32_t *>(blk + (size_t)row * B);
     const int d = align_shift(a, row, t);
+    int8_t *orow = a.slab ? a.slab + (size_t)t * a.slab_stride + (size_t)(row - a.row_begin) * B : packet + moff + (size_t)row * B;
 
     if (tid == 0) {
         // csdrdevice::est_phasecorrect (src/csdrdevice.cc:58-69) for blocks 0..t of this batch:
@@ -368,19 +373,32 @@ __global__ __launch_bounds__(kAlignThreads) void k_align_quant(AlignArgs a)
     // (src/cpacketizer.cc:158-172): y * p, x127, saturate, round-half-even, int8 at the row offset
     if constexpr (VEC) {
         const int8_t *srow = blk + (size_t)row * B;
-        uint4 *o128 = reinterpret_cast<uint4 *>(packet + moff + (size_t)row * B);
+        uint4 *o128 = reinterpret_cast<uint4 *>(orow);
 #pragma unroll 4
         for (int i = v_lo + tid; i < v_hi; i += kAlignThreads) {
             const uint4 sv = shifted_vec(srow, i, d, L, a.xor80);
             o128[i] = make_uint4(rotq_word(sv.x, p), rotq_word(sv.y, p), rotq_word(sv.z, p), rotq_word(sv.w, p));
         }
     } else {
-        uint32_t *o32 = reinterpret_cast<uint32_t *>(packet + moff + (size_t)row * B);
+        uint32_t *o32 = reinterpret_cast<uint32_t *>(orow);
         for (int i = 4 * v_lo + tid; i < 4 * v_hi; i += kAlignThreads) {
             const uint32_t s = (d == 0) ? (s32[i] ^ a.xor80) : shifted_word(s32, i, d, L, a.xor80);
             o32[i] = rotq_word(s, p);
         }
     }
+}
+
+// ---- slab assembly on a gather root ---------------------------------------------------
+// recv [nsrc][nblocks][slab_words] (what an all-to-all of the ranks' slab buffers delivers) -> the matrix rows
+// 1 + src*per .. of packet j.  Pure copy, grid (chunks, nblocks, nsrc).
+template <typename W>
+__global__ void k_assemble_slabs(int8_t *packets, size_t packet_stride, size_t body_off, const W *__restrict__ recv, int nblocks,
+                                 size_t slab_words)
+{
+    const int j = blockIdx.y, src = blockIdx.z;
+    const W *s = recv + ((size_t)src * nblocks + j) * slab_words;
+    W *d = reinterpret_cast<W *>(packets + (size_t)j * packet_stride + body_off) + (size_t)src * slab_words;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < slab_words; i += (size_t)gridDim.x * blockDim.x) d[i] = s[i];
 }
 
 // ---- per-op kernels (class cdsp) ---------------------------------------------------------------

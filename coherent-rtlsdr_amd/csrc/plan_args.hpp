@@ -63,6 +63,12 @@ struct AlignArgs {
     int nrows, B, row_begin, nblocks;
     int digital, refnoise, xcorr_ran;
     uint32_t seq, xor80;
+    // slab output (sharded plans, crsdr_plan_bind_slab): when slab != nullptr the owned rows of block t go to
+    // slab + t*slab_stride (row_begin first, B-byte pitch) instead of the packet matrix, and header + readcnt +
+    // row 0 are written only for blocks hdr_first <= t < hdr_first + hdr_count, into packet (t - hdr_first)
+    int8_t *slab;
+    size_t slab_stride;
+    int hdr_first, hdr_count;
 };
 
 } // namespace crsdr

@@ -6,9 +6,19 @@ and the only exchange step of the path is one gather of the int8 slabs (2 bytes 
 never cf32) plus 16 bytes per row of {lag, mag, phasor}.  torch.distributed is the transport:
 backend "nccl" is RCCL over xGMI on ROCm; "gloo" is used by the CPU tests.
 
-The gather root rotates per block (block b is assembled on rank b mod G): a fixed root would
-ingest (G-1)/G of every block over its own xGMI links and cap scaling; rotating spreads the
-ingest over all ranks.
+The gather root rotates (a fixed root would ingest (G-1)/G of every block over its own xGMI
+links and cap scaling; rotating spreads the ingest over all ranks).  Two exchange shapes:
+
+* per block -- `gather_matrix` / `gather_batch`: block b is assembled on rank b mod G, slabs land
+  in place in the root's packet (one send/recv per block and peer);
+* per batch -- `exchange_batch` (what bench.py runs): the plans write their slabs densely
+  (`crsdr_plan_bind_slab`), so a rank's batch of T blocks is one contiguous [T][rows_per_rank][B]
+  buffer and the whole batch moves with ONE all-to-all: the root rotates in runs, rank q
+  assembles blocks [q*T/G, (q+1)*T/G) of every batch (`batch_root`), and `crsdr_assemble_slabs`
+  copies the received [G][T/G][rows_per_rank][B] chunks into the matrix rows of its T/G packets.
+  Same bytes per xGMI link as the per-block shape, but 1 collective call per batch instead of
+  ~1.75*T point-to-point operations -- at 8 GPUs a rank finishes a block every ~8 us, which
+  per-operation host work cannot keep up with.
 """
 from __future__ import annotations
 
@@ -111,3 +121,33 @@ def gather_scalars(local, slab: Slab, root: int, group=None):
         out = [local[1 + r * per: 1 + (r + 1) * per] for r in range(world)]
         return dist.gather(mine, gather_list=out, dst=root, group=group)
     return dist.gather(mine, gather_list=None, dst=root, group=group)
+
+
+def batch_root(t: int, T: int, world: int) -> int:
+    """Root of block t (index inside a batch of T blocks, T % world == 0) under `exchange_batch`."""
+    if T % world:
+        raise ValueError(f"batch of {T} blocks does not split over {world} ranks")
+    return t // (T // world)
+
+
+def rooted_blocks(T: int, world: int, rank: int) -> range:
+    """The blocks of a batch this rank assembles: the hdr_first / hdr_count of crsdr_plan_bind_slab."""
+    if T % world:
+        raise ValueError(f"batch of {T} blocks does not split over {world} ranks")
+    per = T // world
+    return range(rank * per, (rank + 1) * per)
+
+
+def exchange_batch(recv, send, group=None, async_op: bool = True):
+    """One all-to-all for a whole batch.
+
+    send: this rank's slab buffer, [T][rows_per_rank][B] int8/uint8 contiguous (block t of the batch at
+    index t), written by its plan in slab mode.  recv: same size, receives [G][T/G][rows_per_rank][B]:
+    chunk src = rank src's slabs of the T/G blocks rooted here.  Returns the work handle (async) or None.
+    """
+    import torch.distributed as dist
+
+    world = dist.get_world_size(group)
+    if send.numel() != recv.numel() or send.numel() % world:
+        raise ValueError("send / recv must have equal sizes divisible by the world size")
+    return dist.all_to_all_single(recv.view(-1), send.view(-1), group=group, async_op=async_op)

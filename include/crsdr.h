@@ -207,6 +207,24 @@ int crsdr_plan_device_buffers(crsdr_plan *plan, void **packet, void **lag, void 
  * against a gather in flight is the caller's business. */
 int crsdr_plan_bind_packet(crsdr_plan *plan, void *device_packet, size_t packet_stride);
 
+/* Sharded plans (row_begin / row_count set): slab output for the matrix exchange between GPUs.
+ * With a slab bound, the owned rows of block t of a batch are written densely at
+ *   device_slab + t*slab_stride + (row - row_begin)*blocksize          (slab_stride >= row_count*blocksize)
+ * instead of into the packet matrix, so one rank's batch is a contiguous [nblocks][row_count][blocksize]
+ * buffer -- the send buffer of ONE all-to-all per batch (equal splits: blocks [q*nblocks/G, (q+1)*nblocks/G) go
+ * to rank q).  Header + readcnt + row 0 (cpacketize::write(0, ..), src/ccoherent.cc:253) are written only for
+ * blocks hdr_first <= t < hdr_first + hdr_count -- the blocks this rank assembles -- into packet
+ * (t - hdr_first) of the bound packet buffer.  device_slab = NULL returns to packet output.  No sync. */
+int crsdr_plan_bind_slab(crsdr_plan *plan, void *device_slab, size_t slab_stride, int hdr_first, int hdr_count);
+
+/* On the assembling rank: recv [nsrc][nblocks][(nrows-1)/nsrc][blocksize] int8 (the all-to-all's receive
+ * buffer: chunk src = that rank's slabs of the nblocks blocks assembled here) -> matrix rows 1 + src*per ..
+ * of packet j at device_packets + j*packet_stride.  Replaces the per-row cpacketize::write(c, ..) calls of
+ * src/ccoherent.cc:277 for rows computed on other GPUs.  Device pointers; asynchronous on hip_stream
+ * (a hipStream_t, NULL = the null stream).  Independent of any plan. */
+int crsdr_assemble_slabs(void *device_packets, size_t packet_stride, int nrows, int blocksize, const void *device_recv, int nsrc,
+                         int nblocks, void *hip_stream);
+
 /* With profiling enabled (CRSDR_PROFILE_SUBMIT): elapsed GPU milliseconds on the plan's stream
  * between the start and the end of the most recent submit. */
 int crsdr_plan_last_elapsed_ms(crsdr_plan *plan, float *ms);

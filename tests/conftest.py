@@ -3,6 +3,8 @@ import os
 import sys
 
 import pytest
+import torch  # noqa: F401  -- before libcrsdr.so: torch bundles its own HIP runtime under the same soname, and its
+#                             device init fails when the system runtime (which libcrsdr.so would pull in) is loaded first
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, "oracle")):

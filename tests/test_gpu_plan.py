@@ -397,3 +397,49 @@ def test_digital_mode_centres_the_correlation_peak(b, model):
         assert abs(np.angle(np.sum(y * np.conj(ref)))) < 2e-2
     plan.close()
 
+
+
+@pytest.mark.parametrize("G,aligned", [(2, True), (4, True), (4, False)])
+def test_slab_output_all_to_all_and_assembly_equal_the_single_plan(b, synth, G, aligned):
+    # the multi-GPU exchange shape of bench.py on one device: G sharded plans in slab mode (crsdr_plan_bind_slab)
+    # write dense [T][per][B] buffers; the all-to-all is emulated by indexing (rank q receives chunk q of every
+    # rank's buffer); crsdr_assemble_slabs places the chunks.  Every assembled packet must equal the packet of an
+    # unsharded plan bit for bit -- over two consecutive batches (the EMA / lag state is carried per rank).
+    import torch
+    nsig, L, T = 8, 1024, 4 if G == 4 else 6
+    nrows, B = nsig + 1, 2 * L
+    per, Tg = nsig // G, T // G
+    dev = torch.device("cuda", 0)
+    params = synth.RowParams(nsig, L, 77, dmax=200)
+    blocks = np.stack([synth.make_block(nsig, L, 77, t, params=params)[0] for t in range(2 * T)])
+    full = b.Plan(nrows, B, b.MODE_DIGITAL, max_batch=T)
+    plans = [b.Plan(nrows, B, b.MODE_DIGITAL, row_begin=1 + r * per, row_count=per, max_batch=T) for r in range(G)]
+    pbytes = full.packet_bytes
+    pstride = (pbytes + 255) // 256 * 256
+    skew = 0 if aligned else 4                      # 4-byte aligned only: the word-wise (non-16-byte) kernels
+    send = [torch.zeros(T * per * B + 64, dtype=torch.uint8, device=dev) for _ in range(G)]
+    pk = [torch.zeros(Tg * pstride + 64, dtype=torch.uint8, device=dev) for _ in range(G)]
+    off = [(-(p.data_ptr() + full.matrix_offset)) % 16 + skew for p in pk]
+    soff = [(-s.data_ptr()) % 16 + skew for s in send]
+    for half in range(2):
+        d_in = torch.from_numpy(blocks[half * T:(half + 1) * T].view(np.uint8)).to(dev)
+        full.submit(d_in.data_ptr(), seq=10 + half * T, nblocks=T, block_stride=nrows * B)
+        exp = [full.fetch(block=t)["packet"] for t in range(T)]
+        for r, pl in enumerate(plans):
+            pl.bind_packet(pk[r].data_ptr() + off[r], pstride)
+            pl.bind_slab(send[r].data_ptr() + soff[r], per * B, r * Tg, Tg)
+            pl.submit(d_in.data_ptr(), seq=10 + half * T, nblocks=T, block_stride=nrows * B)
+            pl.sync()
+            with pytest.raises(b.CrsdrError):
+                pl.fetch()                             # packets are not assembled by the plan in slab mode
+            out = pl.fetch(want_packet=False)
+            assert np.array_equal(out["lag"][1 + r * per: 1 + (r + 1) * per], params.d[r * per:(r + 1) * per])
+        for q in range(G):                              # root q: chunk q of every rank's send buffer
+            recv = torch.stack([send[r][soff[r]: soff[r] + T * per * B].view(G, Tg * per * B)[q] for r in range(G)]).contiguous()
+            b.assemble_slabs(pk[q].data_ptr() + off[q], pstride, nrows, B, recv.data_ptr(), G, Tg)
+            torch.cuda.synchronize()
+            for j in range(Tg):
+                got = pk[q][off[q] + j * pstride: off[q] + j * pstride + pbytes].cpu().numpy().view(np.int8)
+                assert np.array_equal(got, exp[q * Tg + j]), (half, q, j)
+    for pl in plans + [full]:
+        pl.close()

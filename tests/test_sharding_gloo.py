@@ -99,6 +99,63 @@ def _worker_batch(rank, world, port, nsig, L, T, outdir):
     dist.destroy_process_group()
 
 
+def _worker_a2a(rank, world, port, nsig, L, T, outdir):
+    """The per-batch exchange shape of bench.py: dense slab buffer -> ONE all_to_all_single -> assemble.
+    The oracle stands in for the plan (it fills the slab buffer the way crsdr_plan_bind_slab does) and plain
+    tensor indexing stands in for crsdr_assemble_slabs (same index contract, tested on the GPU against it)."""
+    for p in (ROOT, os.path.join(ROOT, "oracle")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sharding = importlib.import_module("coherent-rtlsdr_amd.sharding")
+    synth = importlib.import_module("coherent-rtlsdr_amd.synth")
+    import oracle_py as O
+
+    nrows, B = nsig + 1, 2 * L
+    slab = sharding.slab_for_rank(nrows, world, rank)
+    per, Tg = slab.rows_per_rank, T // world
+    params = synth.RowParams(nsig, L, 57, dmax=L // 8)
+    eng = O.Engine(nrows, B, O.DIGITAL)
+    mask = np.zeros(nrows, dtype=np.uint8)
+    mask[slab.row_begin: slab.row_begin + slab.row_count] = 1
+    mine = sharding.rooted_blocks(T, world, rank)
+    send = torch.zeros((T, per, B), dtype=torch.int8)
+    recv = torch.full((world, Tg, per, B), 55, dtype=torch.int8)
+    packets = {}
+    for t in range(T):
+        rows, _ = synth.make_block(nsig, L, 57, t, params=params)
+        out = eng.block(rows, seq=t, lag_mask=mask)
+        m = sharding.matrix_view(torch.from_numpy(out["packet"].copy()), nrows, B)
+        send[t] = m[slab.row_begin: slab.row_begin + slab.row_count]          # slab mode: owned rows only, dense
+        if t in mine:                                                          # header + readcnt + row 0 only where rooted
+            pkt = torch.from_numpy(out["packet"].copy())
+            sharding.matrix_view(pkt, nrows, B)[1:] = 99
+            packets[t] = pkt
+        assert sharding.batch_root(t, T, world) == t // Tg
+    w = sharding.exchange_batch(recv, send, async_op=True)
+    w.wait()
+    for j, t in enumerate(mine):
+        m = sharding.matrix_view(packets[t], nrows, B)
+        for src in range(world):
+            m[1 + src * per: 1 + (src + 1) * per] = recv[src, j]
+        np.save(os.path.join(outdir, f"apkt_{t}.npy"), packets[t].numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_one_all_to_all_per_batch_reassembles_every_packet(world, tmp_path, oracle, synth):
+    nsig, L, T = 8, 256, 8
+    mp.spawn(_worker_a2a, args=(world, _free_port(), nsig, L, T, str(tmp_path)), nprocs=world, join=True)
+    params = synth.RowParams(nsig, L, 57, dmax=L // 8)
+    eng = oracle.Engine(nsig + 1, 2 * L, oracle.DIGITAL)
+    for t in range(T):
+        rows, _ = synth.make_block(nsig, L, 57, t, params=params)
+        exp = eng.block(rows, seq=t)
+        assert np.array_equal(np.load(tmp_path / f"apkt_{t}.npy"), exp["packet"]), t
+
+
 @pytest.mark.parametrize("world", [2, 4])
 def test_batched_rotating_root_exchange(world, tmp_path, oracle, synth):
     # one grouped point-to-point exchange per batch, block b assembled on rank b mod G
