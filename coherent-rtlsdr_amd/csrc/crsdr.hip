@@ -914,6 +914,8 @@ extern "C" int crsdr_plan_submit_batch(crsdr_plan *p, const void *rows, int mem_
         HIP_TRY(hipGetLastError());
         if (pe) HIP_TRY(hipEventRecord(pe[1], S));
     }
+    hipLaunchKernelGGL(k_phase_chain, dim3((p->row_count + 63) / 64), dim3(64), 0, S, aa, p->row_count);
+    HIP_TRY(hipGetLastError());
     {
         hipEvent_t *pe = prof_pair(p, CRSDR_KERNEL_ALIGN_QUANT);
         if (pe) HIP_TRY(hipEventRecord(pe[0], S));

@@ -301,10 +301,38 @@ __device__ __forceinline__ uint32_t rotq_word(uint32_t s, float2 p)
            ((uint32_t)(f32_to_i8_finite(y1.x) & 0xFF) << 16) | ((uint32_t)(f32_to_i8_finite(y1.y) & 0xFF) << 24);
 }
 
+// K2 chain: one thread per owned row walks the batch in block order.
+// csdrdevice::est_phasecorrect (src/csdrdevice.cc:58-69) per block:
+//   phasecorr = conj(corr)/|corr| (:63);  phasecorr = 0.5 phasecorr + 0.5 phasecorrprev (:66-67)
+// |corr| == 0 holds the previous phasor (defined policy; the reference would go NaN for ever).  With the
+// reference noise off the estimate is frozen (src/ccoherent.cc:271) and every block gets phase_in.
+// The chain is sequential in t by definition; doing it once per row here (instead of once per (row, block)
+// workgroup of k_align_quant) keeps the batch cost linear in T.
+__global__ void k_phase_chain(AlignArgs a, int row_count)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= row_count) return;
+    const int row = a.row_begin + i;
+    float2 p = a.phase_in[row];
+    for (int t = 0; t < a.nblocks; ++t) {
+        if (a.refnoise) {
+            const long long sr = a.corr[2 * ((size_t)t * a.nrows + row)], si = a.corr[2 * ((size_t)t * a.nrows + row) + 1];
+            if (sr != 0 || si != 0) {
+                const double cr = (double)sr, ci = (double)si;
+                const double inv = 1.0 / sqrt(cr * cr + ci * ci);
+                const float pr = (float)(cr * inv), pi = (float)(-ci * inv);
+                p = make_float2(__fadd_rn(__fmul_rn(0.5f, pr), __fmul_rn(0.5f, p.x)),
+                                __fadd_rn(__fmul_rn(0.5f, pi), __fmul_rn(0.5f, p.y)));
+            }
+        }
+        a.phasor[(size_t)t * a.nrows + row] = p;
+    }
+    a.phase_out[row] = p;                                   // state carried to the next batch
+}
+
 template <bool VEC>
 __global__ __launch_bounds__(kAlignThreads) void k_align_quant(AlignArgs a)
 {
-    __shared__ float2 sp;
     const int tid = threadIdx.x, t = blockIdx.y;
     const int B = a.B, L = B >> 1;
     const size_t moff = 16 + 4 * (size_t)a.nrows;
@@ -343,31 +371,7 @@ __global__ __launch_bounds__(kAlignThreads) void k_align_quant(AlignArgs a)
     const int d = align_shift(a, row, t);
     int8_t *orow = a.slab ? a.slab + (size_t)t * a.slab_stride + (size_t)(row - a.row_begin) * B : packet + moff + (size_t)row * B;
 
-    if (tid == 0) {
-        // csdrdevice::est_phasecorrect (src/csdrdevice.cc:58-69) for blocks 0..t of this batch:
-        //   phasecorr = conj(corr)/|corr| (:63);  phasecorr = 0.5 phasecorr + 0.5 phasecorrprev (:66-67)
-        // |corr| == 0 holds the previous phasor (defined policy; the reference would go NaN for ever).
-        float2 p = a.phase_in[row];
-        if (a.refnoise) {
-            for (int u = 0; u <= t; ++u) {
-                const long long sr = a.corr[2 * ((size_t)u * a.nrows + row)], si = a.corr[2 * ((size_t)u * a.nrows + row) + 1];
-                if (sr != 0 || si != 0) {
-                    const double cr = (double)sr, ci = (double)si;
-                    const double inv = 1.0 / sqrt(cr * cr + ci * ci);
-                    const float pr = (float)(cr * inv), pi = (float)(-ci * inv);
-                    p = make_float2(__fadd_rn(__fmul_rn(0.5f, pr), __fmul_rn(0.5f, p.x)),
-                                    __fadd_rn(__fmul_rn(0.5f, pi), __fmul_rn(0.5f, p.y)));
-                }
-            }
-        }
-        if (blockIdx.z == 0) {
-            a.phasor[(size_t)t * a.nrows + row] = p;       // get_phasecorrect() after block t
-            if (t == a.nblocks - 1) a.phase_out[row] = p;  // state carried to the next batch
-        }
-        sp = p;
-    }
-    __syncthreads();
-    const float2 p = sp;
+    const float2 p = a.phasor[(size_t)t * a.nrows + row];      // get_phasecorrect() after block t (k_phase_chain)
 
     // csdrdevice::phasecorrect (src/csdrdevice.cc:80-84) + cpacketize::write(complex<float>*)
     // (src/cpacketizer.cc:158-172): y * p, x127, saturate, round-half-even, int8 at the row offset
