@@ -839,6 +839,7 @@ extern "C" int crsdr_plan_submit_batch(crsdr_plan *p, const void *rows, int mem_
     aa.xcorr_ran = any_lag ? 1 : 0;
     aa.seq = seq; aa.xor80 = xor80;
     aa.slab = p->d_slab; aa.slab_stride = p->slab_stride; aa.hdr_first = p->hdr_first; aa.hdr_count = p->hdr_count;
+    aa.lag_out = p->d_lag; aa.mag_out = p->d_mag; aa.frac_out = p->d_frac; aa.mag_state = p->d_mag_state; aa.frac_state = p->d_frac_state;
 
     if (any_lag && p->longblock) {
         // B = N1 x 16384: column FFTs -> row FFTs (x conj ref, inverse) -> inverse column FFTs + argmax -> finalize

@@ -313,6 +313,15 @@ __global__ void k_phase_chain(AlignArgs a, int row_count)
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= row_count) return;
     const int row = a.row_begin + i;
+    if (!a.xcorr_ran) {
+        // no lag was measured in this batch: get_lagp() still returns the last one (include/csdrdevice.h:161)
+        const int32_t lg = a.lag_state[row];
+        const float mg = a.mag_state[row], fr = a.frac_state[row];
+        for (int t = 0; t < a.nblocks; ++t) {
+            const size_t o = (size_t)t * a.nrows + row;
+            a.lag_out[o] = lg; a.mag_out[o] = mg; a.frac_out[o] = fr;
+        }
+    }
     float2 p = a.phase_in[row];
     for (int t = 0; t < a.nblocks; ++t) {
         if (a.refnoise) {

@@ -69,6 +69,11 @@ struct AlignArgs {
     int8_t *slab;
     size_t slab_stride;
     int hdr_first, hdr_count;
+    // per-block {lag, mag, frac} outputs and the carried state: a batch whose cross-correlation did not run
+    // (CRSDR_NO_LAG / nothing requested) republishes the state for every block (k_phase_chain)
+    int32_t *lag_out;
+    float *mag_out, *frac_out;
+    const float *mag_state, *frac_state;
 };
 
 } // namespace crsdr
