@@ -776,6 +776,8 @@ extern "C" int crsdr_plan_submit_batch(crsdr_plan *p, const void *rows, int mem_
     const size_t B = (size_t)p->B, n = (size_t)p->nrows, T = (size_t)nblocks;
     if (block_stride == 0) block_stride = n * B;
     if (block_stride < n * B) return fail(CRSDR_EINVAL, "plan_submit: block_stride smaller than one block");
+    if (mem_kind == CRSDR_MEM_DEVICE && ((uintptr_t)rows % 4 || block_stride % 4))
+        return fail(CRSDR_EINVAL, "plan_submit: device rows and block_stride must be 4-byte aligned (16-byte for the vector kernels)");
     HIP_TRY(hipSetDevice(p->device));
     hipStream_t S = p->stream, A = p->aux;
     const uint32_t xor80 = (flags & CRSDR_OFFSET_BINARY) ? 0x80808080u : 0u;

@@ -443,3 +443,44 @@ def test_slab_output_all_to_all_and_assembly_equal_the_single_plan(b, synth, G, 
                 assert np.array_equal(got, exp[q * Tg + j]), (half, q, j)
     for pl in plans + [full]:
         pl.close()
+
+
+@pytest.mark.parametrize("B", [1024, 16384, 1 << 15])
+def test_device_input_and_bound_packet_alignments(b, synth, B):
+    # caller-owned device memory (CRSDR_MEM_DEVICE + crsdr_plan_bind_packet): 16-byte aligned pointers take the
+    # 16-byte vector kernels, 4-byte aligned ones the word kernels, anything else is refused.  Every combination
+    # must reproduce the host-buffer result bit for bit, with a block stride larger than one block.
+    import torch
+    nsig, L, T = 4, B // 2, 1 if B > 16384 else 3
+    nrows = nsig + 1
+    params = synth.RowParams(nsig, L, 91, dmax=L // 8)
+    blocks = np.stack([synth.make_block(nsig, L, 91, t, params=params)[0] for t in range(T)])
+    ref = b.Plan(nrows, B, b.MODE_DIGITAL, max_batch=T)
+    ref.submit(blocks if T > 1 else blocks[0], seq=5)
+    exp = [ref.fetch(block=t) for t in range(T)]
+    dev = torch.device("cuda", 0)
+    stride = nrows * B + 64
+    pstride = (ref.packet_bytes + 3) // 4 * 4 + 32
+    for in_off, pk_off in ((0, 0), (4, 0), (0, 8), (12, 4)):
+        raw = torch.zeros(T * stride + 64, dtype=torch.uint8, device=dev)
+        base = (-raw.data_ptr()) % 16 + in_off
+        for t in range(T):
+            raw[base + t * stride: base + t * stride + nrows * B] = torch.from_numpy(blocks[t].view(np.uint8).reshape(-1)).to(dev)
+        pk = torch.zeros(T * pstride + 64, dtype=torch.uint8, device=dev)
+        pbase = (-(pk.data_ptr() + ref.matrix_offset)) % 16 + pk_off
+        plan = b.Plan(nrows, B, b.MODE_DIGITAL, max_batch=T)
+        plan.bind_packet(pk.data_ptr() + pbase, pstride)
+        plan.submit(raw.data_ptr() + base, seq=5, nblocks=T, block_stride=stride)
+        plan.sync()
+        for t in range(T):
+            got = plan.fetch(block=t)
+            for k in ("lag", "mag", "frac", "phasor", "packet"):
+                assert np.array_equal(got[k], exp[t][k]), (in_off, pk_off, t, k)
+            mine = pk[pbase + t * pstride: pbase + t * pstride + ref.packet_bytes].cpu().numpy().view(np.int8)
+            assert np.array_equal(mine, exp[t]["packet"]), (in_off, pk_off, t)
+        with pytest.raises(b.CrsdrError):
+            plan.submit(raw.data_ptr() + base + 1, seq=5, nblocks=T, block_stride=stride)      # not 4-byte aligned
+        with pytest.raises(b.CrsdrError):
+            plan.bind_packet(pk.data_ptr() + pbase + 2, pstride)
+        plan.close()
+    ref.close()
