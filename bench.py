@@ -257,7 +257,7 @@ def main():
                            "hbm_read_frac": A_block * blocks_per_s / (world * HBM_PEAK_GBS * 1e9)},
             "kernel_ms": {k: (float(np.mean(v)) if len(v) else None) for k, v in k_ms.items()},
             "lags_exact": lags_ok, "matrix_assembled": assembled_ok if world > 1 else None,
-            "env": _env(torch, dev),
+            "env": _env(torch, dev, b, local_rank),
         }
 
     # ---- extras: locked steady state (phase path only) ---------------------------------------------
@@ -296,18 +296,24 @@ def main():
     # ---- extra: host-buffer (PCIe-inclusive) rate -- reported for DESIGN.md, never `value` -----------
     if not args.no_extras and world == 1:
         hp = b.Plan(nrows, B, mode, device=local_rank, max_batch=T)
-        hrows = np.ascontiguousarray(np.broadcast_to(host_block0, (T, nrows, B)))
-        hp.submit(hrows, seq=0)
-        hp.fetch()
-        t0 = time.perf_counter()
-        nh = 3
-        for i in range(nh):
-            hp.submit(hrows, seq=i * T)
-            hp.fetch()                      # D2H of the last packet; one packet per batch is copied back
-        dth = time.perf_counter() - t0
-        result["pcie_inclusive"] = {"blocks_per_s": nh * T / dth, "note": f"pageable host int8 in ({T} blocks per submit), "
-                                    "host packet of the last block out; PCIe Gen5 x16"}
+        pinned = b.PinnedArray((T, nrows, B), np.int8)           # crsdr_host_alloc: what a C host would hand over
+        pinned.array[:] = host_block0
+        pageable = np.ascontiguousarray(np.broadcast_to(host_block0, (T, nrows, B)))
+        res = {}
+        for name, hrows in (("pageable", pageable), ("pinned", pinned.array)):
+            hp.submit(hrows, seq=0)
+            hp.fetch()
+            t0 = time.perf_counter()
+            nh = 3
+            for i in range(nh):
+                hp.submit(hrows, seq=i * T)
+                hp.fetch()                  # D2H of the last packet; one packet per batch is copied back
+            res[name] = nh * T / (time.perf_counter() - t0)
+        result["pcie_inclusive"] = {"blocks_per_s": res["pinned"], "pageable_blocks_per_s": res["pageable"],
+                                    "note": f"host int8 in ({T} blocks per submit; page-locked via crsdr_host_alloc vs pageable numpy), "
+                                            "host packet of the last block out; PCIe Gen5 x16, 16.8 MB per block each way at most"}
         hp.close()
+        pinned.close()
 
     # ---- CPU baseline: the oracle (C port of the reference path) on this host's cores --------------
     if rank == 0 and not args.no_cpu_baseline and world == 1:
@@ -336,7 +342,7 @@ def _make_slab(synth, params, nsig, L, seed, t, slab):
     return rows, None
 
 
-def _env(torch, dev):
+def _env(torch, dev, b, local_rank):
     """GPU and host the numbers were taken on (clocks recorded)."""
     p = torch.cuda.get_device_properties(dev)
     cpu = None
@@ -347,9 +353,9 @@ def _env(torch, dev):
                 break
     except OSError:
         pass
-    clk = getattr(p, "clock_rate", None)
-    return {"gpu": p.name, "arch": getattr(p, "gcnArchName", None), "cus": p.multi_processor_count,
-            "gpu_max_clock_mhz": clk / 1e3 if clk else None, "hbm_gib": round(p.total_memory / 2**30, 1),
+    info = b.device_info(local_rank)
+    return {"gpu": info["name"], "arch": getattr(p, "gcnArchName", None), "cus": p.multi_processor_count,
+            "gpu_max_clock_mhz": info["clock_mhz"], "hbm_clock_mhz": info["memory_clock_mhz"], "hbm_gib": round(p.total_memory / 2**30, 1),
             "cpu": cpu, "host_cores": len(os.sched_getaffinity(0)), "torch": torch.__version__}
 
 
@@ -377,7 +383,7 @@ def _cpu_baseline(args, rows, nrows, B, mode):
     t0 = time.perf_counter()
     eng.block(rows, want_packet=True)
     one = time.perf_counter() - t0
-    nb = args.cpu_blocks or max(1, min(16, int(10.0 / max(one, 1e-3))))
+    nb = args.cpu_blocks or max(1, min(64, int(12.0 / max(one, 1e-3))))
     t0 = time.perf_counter()
     for i in range(nb):
         eng.block(rows, seq=i)

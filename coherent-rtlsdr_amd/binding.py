@@ -30,6 +30,7 @@ ABI_SYMBOLS = [
     "crsdr_plan_last_elapsed_ms", "crsdr_plan_enable_profiling", "crsdr_plan_kernel_times",
     "crsdr_plan_submit_batch", "crsdr_plan_fetch_block", "crsdr_plan_packet_stride", "crsdr_covariance",
     "crsdr_noisesubspace", "crsdr_pmusic2d", "crsdr_plan_bind_slab", "crsdr_assemble_slabs",
+    "crsdr_device_info", "crsdr_host_alloc", "crsdr_host_free",
 ]
 KERNEL_REF_SPECTRUM, KERNEL_XCORR_LAG, KERNEL_PHASE_DOT, KERNEL_ALIGN_QUANT = 0, 1, 2, 3
 
@@ -77,6 +78,9 @@ def lib():
     L.crsdr_abi_version.restype = C.c_int
     L.crsdr_last_error.restype = C.c_char_p
     L.crsdr_device_count.argtypes = [C.POINTER(C.c_int)]
+    L.crsdr_host_alloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
+    L.crsdr_host_free.argtypes = [C.c_void_p]
+    L.crsdr_device_info.argtypes = [C.c_int, C.c_char_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_size_t)]
     L.crsdr_convtosigned.argtypes = [u8p, u8p, C.c_int]
     L.crsdr_convtofloat.argtypes = [f32p, i8p, C.c_int]
     L.crsdr_scalarmul.argtypes = [f32p, f32p, C.c_float, C.c_float, C.c_int]
@@ -133,6 +137,37 @@ def device_count() -> int:
     n = C.c_int(0)
     rc = lib().crsdr_device_count(C.byref(n))
     return n.value if rc == 0 else 0
+
+
+def device_info(device: int = 0) -> dict:
+    name = C.create_string_buffer(256)
+    cus, clk, mclk, mem = C.c_int(0), C.c_int(0), C.c_int(0), C.c_size_t(0)
+    _check(lib().crsdr_device_info(int(device), name, 256, C.byref(cus), C.byref(clk), C.byref(mclk), C.byref(mem)))
+    return {"name": name.value.decode(errors="replace"), "compute_units": cus.value, "clock_mhz": clk.value / 1e3,
+            "memory_clock_mhz": mclk.value / 1e3, "memory_gib": round(mem.value / 2**30, 1)}
+
+
+class PinnedArray:
+    """numpy view of page-locked host memory from crsdr_host_alloc (freed on close / garbage collection)."""
+
+    def __init__(self, shape, dtype=np.int8):
+        self.shape, self.dtype = tuple(np.atleast_1d(shape)), np.dtype(dtype)
+        nbytes = int(np.prod(self.shape)) * self.dtype.itemsize
+        self._ptr = C.c_void_p()
+        _check(lib().crsdr_host_alloc(C.byref(self._ptr), nbytes))
+        self.array = np.frombuffer((C.c_uint8 * nbytes).from_address(self._ptr.value), dtype=self.dtype).reshape(self.shape)
+
+    def close(self):
+        if self._ptr:
+            self.array = None
+            lib().crsdr_host_free(self._ptr)
+            self._ptr = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 # ---- per-op wrappers (class cdsp), numpy host arrays in / out ----------------------------------

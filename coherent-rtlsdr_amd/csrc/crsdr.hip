@@ -52,6 +52,40 @@ extern "C" int crsdr_device_count(int *count)
     return CRSDR_OK;
 }
 
+extern "C" int crsdr_device_info(int device, char *name, int name_cap, int *compute_units, int *clock_khz, int *memory_clock_khz,
+                                 size_t *memory_bytes)
+{
+    int n = 0;
+    int rc = crsdr_device_count(&n);
+    if (rc) return rc;
+    if (device < 0 || device >= n) return fail(CRSDR_ENODEV, "device_info: device %d of %d", device, n);
+    hipDeviceProp_t pr;
+    HIP_TRY(hipGetDeviceProperties(&pr, device));
+    if (name && name_cap > 0) { snprintf(name, (size_t)name_cap, "%s (%s)", pr.name, pr.gcnArchName); }
+    if (compute_units) *compute_units = pr.multiProcessorCount;
+    if (clock_khz) *clock_khz = pr.clockRate;
+    if (memory_clock_khz) *memory_clock_khz = pr.memoryClockRate;
+    if (memory_bytes) *memory_bytes = pr.totalGlobalMem;
+    return CRSDR_OK;
+}
+
+static int require_device();
+extern "C" int crsdr_host_alloc(void **ptr, size_t bytes)
+{
+    if (!ptr || !bytes) return fail(CRSDR_EINVAL, "host_alloc: NULL pointer or zero size");
+    *ptr = nullptr;
+    { int rc_ = require_device(); if (rc_) return rc_; }
+    hipError_t e = hipHostMalloc(ptr, bytes, hipHostMallocDefault);
+    if (e != hipSuccess) { *ptr = nullptr; return fail(e == hipErrorOutOfMemory ? CRSDR_ENOMEM : CRSDR_EHIP, "hipHostMalloc(%zu): %s", bytes, hipGetErrorString(e)); }
+    return CRSDR_OK;
+}
+extern "C" int crsdr_host_free(void *ptr)
+{
+    if (!ptr) return CRSDR_OK;
+    HIP_TRY(hipHostFree(ptr));
+    return CRSDR_OK;
+}
+
 static int require_device()
 {
     int n = 0;

@@ -25,7 +25,8 @@ class ccoherent {
     int blocksize, nrows, mode;
     crsdr_plan *plan;
     std::vector<csdrdevice *> lagqueue;
-    std::vector<int8_t> rows, packet;
+    int8_t *rows, *packet;          // page-locked (crsdr_host_alloc), the engine-owned buffers of src/ccoherent.cc:44-47
+    size_t packet_bytes;
     std::vector<uint32_t> readcnt;
     std::vector<uint8_t> mask;
     std::vector<int32_t> lag;

@@ -48,6 +48,17 @@ enum {
 int crsdr_abi_version(void);
 const char *crsdr_last_error(void);
 int crsdr_device_count(int *count);
+/* Page-locked host memory for the rows / packet buffers handed to crsdr_plan_submit / crsdr_plan_fetch with
+ * CRSDR_MEM_HOST -- the role volk_malloc / fftwf_alloc_complex play in the reference (src/ccoherent.cc:44-47,
+ * 66-69: aligned allocations owned by the engine).  Pageable memory works too, at roughly half the PCIe rate
+ * and with host-blocking copies. */
+int crsdr_host_alloc(void **ptr, size_t bytes);
+int crsdr_host_free(void *ptr);
+
+/* Name, compute units, engine / memory clocks (kHz) and memory size of a device, for benchmark records
+ * ("GPU clocks recorded").  Any output pointer may be NULL; name is NUL-terminated in name_cap bytes. */
+int crsdr_device_info(int device, char *name, int name_cap, int *compute_units, int *clock_khz, int *memory_clock_khz,
+                      size_t *memory_bytes);
 
 /* ------------------------------------------------------------------------------------------
  * (i) per-op entry points == class cdsp (include/cdsp.h:36-71).  Host pointers in and out;
