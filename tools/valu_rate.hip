@@ -28,6 +28,26 @@ __global__ __launch_bounds__(256) void k(float *out, int iters)
             REP16(asm volatile("v_pk_add_f32 %0, %0, %8\n v_pk_add_f32 %1, %1, %8\n v_pk_add_f32 %2, %2, %8\n v_pk_add_f32 %3, %3, %8\n"
                                "v_pk_add_f32 %4, %4, %8\n v_pk_add_f32 %5, %5, %8\n v_pk_add_f32 %6, %6, %8\n v_pk_add_f32 %7, %7, %8\n"
                                : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3), "+v"(p4), "+v"(p5), "+v"(p6), "+v"(p7) : "v"(pb));)
+        } else if (KIND == 5) { // v_mul_f32 (VOP2)
+            REP16(asm volatile("v_mul_f32 %0, %0, %8\n v_mul_f32 %1, %1, %8\n v_mul_f32 %2, %2, %8\n v_mul_f32 %3, %3, %8\n"
+                               "v_mul_f32 %4, %4, %8\n v_mul_f32 %5, %5, %8\n v_mul_f32 %6, %6, %8\n v_mul_f32 %7, %7, %8\n"
+                               : "+v"(s0), "+v"(s1), "+v"(s2), "+v"(s3), "+v"(s4), "+v"(s5), "+v"(s6), "+v"(s7) : "v"(b));)
+        } else if (KIND == 6) { // v_fmac_f32 (VOP2: D = S0*S1 + D)
+            REP16(asm volatile("v_fmac_f32 %0, %8, %9\n v_fmac_f32 %1, %8, %9\n v_fmac_f32 %2, %8, %9\n v_fmac_f32 %3, %8, %9\n"
+                               "v_fmac_f32 %4, %8, %9\n v_fmac_f32 %5, %8, %9\n v_fmac_f32 %6, %8, %9\n v_fmac_f32 %7, %8, %9\n"
+                               : "+v"(s0), "+v"(s1), "+v"(s2), "+v"(s3), "+v"(s4), "+v"(s5), "+v"(s6), "+v"(s7) : "v"(b), "v"(a));)
+        } else if (KIND == 7) { // complex multiply as 2 packed ops with op_sel / neg_lo (x * w, 4 independent chains x 2 instr)
+            REP16(asm volatile("v_pk_mul_f32 %4, %0, %8 op_sel_hi:[0,1]\n v_pk_fma_f32 %0, %0, %8, %4 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0]\n"
+                               "v_pk_mul_f32 %5, %1, %8 op_sel_hi:[0,1]\n v_pk_fma_f32 %1, %1, %8, %5 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0]\n"
+                               "v_pk_mul_f32 %6, %2, %8 op_sel_hi:[0,1]\n v_pk_fma_f32 %2, %2, %8, %6 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0]\n"
+                               "v_pk_mul_f32 %7, %3, %8 op_sel_hi:[0,1]\n v_pk_fma_f32 %3, %3, %8, %7 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0]\n"
+                               : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3), "+v"(p4), "+v"(p5), "+v"(p6), "+v"(p7) : "v"(pb));)
+        } else if (KIND == 8) { // the same complex multiply as 4 scalar ops: 2 v_mul + 2 v_fmac per product, 4 chains
+            REP16(asm volatile("v_mul_f32 %4, %0, %8\n v_mul_f32 %5, %0, %9\n v_fmac_f32 %4, %1, %9\n v_fmac_f32 %5, %1, %8\n"
+                               "v_mul_f32 %6, %2, %8\n v_mul_f32 %7, %2, %9\n v_fmac_f32 %6, %3, %9\n v_fmac_f32 %7, %3, %8\n"
+                               "v_mul_f32 %0, %4, %8\n v_mul_f32 %1, %4, %9\n v_fmac_f32 %0, %5, %9\n v_fmac_f32 %1, %5, %8\n"
+                               "v_mul_f32 %2, %6, %8\n v_mul_f32 %3, %6, %9\n v_fmac_f32 %2, %7, %9\n v_fmac_f32 %3, %7, %8\n"
+                               : "+v"(s0), "+v"(s1), "+v"(s2), "+v"(s3), "+v"(s4), "+v"(s5), "+v"(s6), "+v"(s7) : "v"(b), "v"(a));)
         } else { // v_pk_mul_f32
             REP16(asm volatile("v_pk_mul_f32 %0, %0, %8\n v_pk_mul_f32 %1, %1, %8\n v_pk_mul_f32 %2, %2, %8\n v_pk_mul_f32 %3, %3, %8\n"
                                "v_pk_mul_f32 %4, %4, %8\n v_pk_mul_f32 %5, %5, %8\n v_pk_mul_f32 %6, %6, %8\n v_pk_mul_f32 %7, %7, %8\n"
@@ -39,13 +59,14 @@ __global__ __launch_bounds__(256) void k(float *out, int iters)
 }
 template <int KIND> void run(const char *name, int wavesPerSimd)
 {
+    // kinds 7 / 8 issue 8 resp. 16 instructions per REP16 element instead of 8: scaled below
     float *d; hipMalloc(&d, 4);
     const int iters = 2000, blocks = 256 * wavesPerSimd; // 256-thread blocks = 4 waves = 1 per SIMD
     hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
     k<KIND><<<blocks, 256>>>(d, 10); hipDeviceSynchronize();
     hipEventRecord(a); k<KIND><<<blocks, 256>>>(d, iters); hipEventRecord(b); hipEventSynchronize(b);
     float ms; hipEventElapsedTime(&ms, a, b);
-    double instr_per_simd = (double)iters * 128 * wavesPerSimd; // wave-instructions each SIMD executes
+    double instr_per_simd = (double)iters * (KIND == 8 ? 256 : 128) * wavesPerSimd; // wave-instructions each SIMD executes
     double ns_per_instr = ms * 1e6 / instr_per_simd;
     printf("%-14s waves/SIMD=%d  %.3f ms  %.3f ns per wave-instr per SIMD  (= %.2f cyc @2.4GHz)\n", name, wavesPerSimd, ms, ns_per_instr, ns_per_instr * 2.4);
     hipFree(d);
@@ -53,9 +74,8 @@ template <int KIND> void run(const char *name, int wavesPerSimd)
 int main()
 {
     for (int w : {1, 2, 4}) {
-        if (w == 1) { run<0>("v_fma_f32", 1); run<1>("v_pk_fma_f32", 1); run<2>("v_add_f32", 1); run<3>("v_pk_add_f32", 1); run<4>("v_pk_mul_f32", 1); }
-        if (w == 2) { run<0>("v_fma_f32", 2); run<1>("v_pk_fma_f32", 2); run<2>("v_add_f32", 2); run<3>("v_pk_add_f32", 2); run<4>("v_pk_mul_f32", 2); }
-        if (w == 4) { run<0>("v_fma_f32", 4); run<1>("v_pk_fma_f32", 4); run<2>("v_add_f32", 4); run<3>("v_pk_add_f32", 4); run<4>("v_pk_mul_f32", 4); }
+        run<0>("v_fma_f32", w); run<1>("v_pk_fma_f32", w); run<2>("v_add_f32", w); run<3>("v_pk_add_f32", w); run<4>("v_pk_mul_f32", w);
+        run<5>("v_mul_f32", w); run<6>("v_fmac_f32", w); run<7>("cmul 2x pk", w); run<8>("cmul 4x scalar", w);
     }
     return 0;
 }
