@@ -191,6 +191,15 @@ static hipError_t launch_ref_spectrum14(hipStream_t s, int nblocks, const int8_t
 
 static hipError_t launch_xcorr_lag14(hipStream_t s, const XcorrArgs &a, int row_count, const float2 *twA, const float2 *twB)
 {
+    // CRSDR_K1_VARIANT: "half" = two rows per CU (xcorr14h.hpp), "full" = one 128 KiB row per CU (xcorr14.hpp)
+    static const bool half = [] { const char *v = getenv("CRSDR_K1_VARIANT"); return v ? (v[0] == 'h') : false; }();
+    if (half) {
+        auto kh = x14h::k_xcorr_lag14h;
+        hipError_t eh = hipFuncSetAttribute((const void *)kh, hipFuncAttributeMaxDynamicSharedMemorySize, x14h::LDS_BYTES_H);
+        if (eh != hipSuccess) return eh;
+        hipLaunchKernelGGL(kh, dim3(row_count, a.nblocks), dim3(x14h::THREADS_H), x14h::LDS_BYTES_H, s, a, twA, twB);
+        return hipGetLastError();
+    }
     auto kern = x14::k_xcorr_lag14;
     hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, x14::LDS_BYTES);
     if (e != hipSuccess) return e;

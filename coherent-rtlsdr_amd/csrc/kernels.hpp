@@ -22,6 +22,7 @@
 #include "fft_lds.hpp"
 #include "plan_args.hpp"
 #include "xcorr14.hpp"
+#include "xcorr14h.hpp"
 #include "longblock.hpp"
 #include "covariance.hpp"
 #include "music.hpp"

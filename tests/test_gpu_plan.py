@@ -484,3 +484,38 @@ def test_device_input_and_bound_packet_alignments(b, synth, B):
             plan.bind_packet(pk.data_ptr() + pbase + 2, pstride)
         plan.close()
     ref.close()
+
+
+def test_half_row_k1_variant_matches_the_default_kernel(tmp_path):
+    # CRSDR_K1_VARIANT=half selects xcorr14h.hpp (two rows per CU, even / odd plane trips through 66 KiB of LDS).
+    # The variant is chosen once per process, so it runs in a child: same lags, mag within 1e-5 (the last pass is
+    # decimation-in-time instead of -in-frequency), same packets except +-1 LSB at rounding boundaries.
+    import subprocess, sys, textwrap
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = textwrap.dedent('''
+        import importlib, sys, numpy as np
+        sys.path.insert(0, %r)
+        pkg = importlib.import_module("coherent-rtlsdr_amd")
+        b, synth = pkg.binding, pkg.synth
+        nsig, L, T = 37, 8192, 3
+        params = synth.RowParams(nsig, L, 4242, dmax=2000)
+        blocks = np.stack([synth.make_block(nsig, L, 4242, t, params=params)[0] for t in range(T)])
+        plan = b.Plan(nsig + 1, 2 * L, b.MODE_DIGITAL, max_batch=T)
+        plan.submit(blocks, seq=3)
+        outs = [plan.fetch(block=t) for t in range(T)]
+        np.savez(sys.argv[1], lag=np.stack([o["lag"] for o in outs]), mag=np.stack([o["mag"] for o in outs]),
+                 frac=np.stack([o["frac"] for o in outs]), packet=np.stack([o["packet"] for o in outs]), d=params.d)
+    ''') % root
+    res = {}
+    for variant in ("full", "half"):
+        out = tmp_path / f"{variant}.npz"
+        env = dict(os.environ, CRSDR_K1_VARIANT=variant)
+        r = subprocess.run([sys.executable, "-c", code, str(out)], env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stdout + r.stderr
+        res[variant] = np.load(out)
+    f, h = res["full"], res["half"]
+    assert np.array_equal(h["lag"], f["lag"]) and np.array_equal(h["lag"][0, 1:], f["d"])
+    assert np.allclose(h["mag"], f["mag"], rtol=1e-5)
+    assert np.allclose(h["frac"], f["frac"], atol=1e-3)
+    d = h["packet"].astype(np.int16) - f["packet"].astype(np.int16)
+    assert np.abs(d).max() <= 1 and np.count_nonzero(d) <= 1e-4 * d.size
