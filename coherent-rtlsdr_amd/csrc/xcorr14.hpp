@@ -268,20 +268,18 @@ __global__ __launch_bounds__(THREADS, 2) void k_ref_spectrum14(const int8_t *__r
 }
 
 // ---- K1 -------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(THREADS, 2) void k_xcorr_lag14(XcorrArgs a, const float2 *__restrict__ twA,
-                                                            const float2 *__restrict__ twB)
+// One row of K1; src = the int8 row.
+__device__ __forceinline__ void xcorr_row14(const XcorrArgs &a, unsigned char *smem, const int8_t *__restrict__ src, int row, int t,
+                                            const float2 *__restrict__ twA, const float2 *__restrict__ twB)
 {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float2 *A = reinterpret_cast<float2 *>(smem);
     float4 *A4 = reinterpret_cast<float4 *>(smem);
     float *red = reinterpret_cast<float *>(smem + (size_t)LDS_ELEMS * 8); // 128 floats of scratch
     const int tid = threadIdx.x;
-    const int row = a.row_begin + blockIdx.x, t = blockIdx.y;
-    if (xcorr_skip(a, row, t, tid)) return;
     const float4 *__restrict__ refspec4 = reinterpret_cast<const float4 *>(a.refspec) + (size_t)t * (N / 2);
 
     CRSDR_STAMP(0);
-    pass0_forward<false>(A, a.rows + (size_t)t * a.block_stride + (size_t)row * N, twA, a.xor80, tid);
+    pass0_forward<false>(A, src, twA, a.xor80, tid);
     CRSDR_STAMP(1);
     // P1 / P1' twiddles: one chain per row, computed while the P0 stores drain, alive across J
     float2 wB[32];
@@ -400,6 +398,15 @@ __global__ __launch_bounds__(THREADS, 2) void k_xcorr_lag14(XcorrArgs a, const f
         xcorr_publish(a, row, t, gi - L /* src/ccoherent.cc:232 */, sqrtf(gm / (float)L) * kInvScale2 /* :204 */, D);
     }
     CRSDR_STAMP(8);
+}
+
+__global__ __launch_bounds__(THREADS, 2) void k_xcorr_lag14(XcorrArgs a, const float2 *__restrict__ twA,
+                                                            const float2 *__restrict__ twB)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int row = a.row_begin + blockIdx.x, t = blockIdx.y;
+    if (xcorr_skip(a, row, t, threadIdx.x)) return;
+    xcorr_row14(a, smem, a.rows + (size_t)t * a.block_stride + (size_t)row * N, row, t, twA, twB);
 }
 
 // ---- 16384-point row transforms on cf32 lines (stage B of the long-block path, longblock.hpp) ---------
