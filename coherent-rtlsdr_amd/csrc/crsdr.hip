@@ -553,6 +553,8 @@ struct crsdr_plan {
     float *d_mag = nullptr, *d_frac = nullptr, *d_mag_state = nullptr, *d_frac_state = nullptr;
     float2 *d_phasor = nullptr, *d_phase_state[2] = {nullptr, nullptr}; // [T][nrows], 2 x [nrows]
     long long *d_corr = nullptr;       // [T][nrows][2]
+    unsigned int *d_sync = nullptr;    // fused K2: [0] ticket counter, [1] status
+    bool fused_k2 = true, fused_used = false;
     int phase_cur = 0;
     int last_nblocks = 0;
     // long-block path (B > 16384): B = N1 x 16384
@@ -653,6 +655,9 @@ static int plan_alloc(crsdr_plan *p)
     HIP_TRY(hipMalloc((void **)&p->d_frac, sizeof(float) * n * T));
     HIP_TRY(hipMalloc((void **)&p->d_phasor, sizeof(float2) * n * T));
     HIP_TRY(hipMalloc((void **)&p->d_corr, sizeof(long long) * 2 * n * T));
+    HIP_TRY(hipMalloc((void **)&p->d_sync, 64));
+    HIP_TRY(hipMemset(p->d_sync, 0, 64));
+    { const char *e = getenv("CRSDR_K2_FUSED"); if (e) p->fused_k2 = atoi(e) != 0; }
     HIP_TRY(hipMalloc((void **)&p->d_lag_state, sizeof(int32_t) * n));
     HIP_TRY(hipMalloc((void **)&p->d_mag_state, sizeof(float) * n));
     HIP_TRY(hipMalloc((void **)&p->d_frac_state, sizeof(float) * n));
@@ -669,7 +674,7 @@ static void plan_free(crsdr_plan *p)
     if (p->own_stream) (void)hipStreamSynchronize(p->own_stream);
     if (p->aux) (void)hipStreamSynchronize(p->aux);
     void *bufs[] = {p->d_wc, p->d_wf, p->d_tw1, p->d_Y, p->d_Yref, p->d_part, p->d_tw, p->d_twA, p->d_twB, p->d_refspec[0], p->d_refspec[1], p->d_rows, p->d_packet_alloc, p->d_readcnt,
-                    p->d_mask, p->d_lag, p->d_mag, p->d_frac, p->d_phasor, p->d_corr, p->d_lag_state, p->d_mag_state,
+                    p->d_mask, p->d_lag, p->d_mag, p->d_frac, p->d_phasor, p->d_corr, p->d_sync, p->d_lag_state, p->d_mag_state,
                     p->d_frac_state, p->d_phase_state[0], p->d_phase_state[1]};
     for (void *b : bufs) if (b) (void)hipFree(b);
     if (p->h_readcnt) (void)hipHostFree(p->h_readcnt);
@@ -725,13 +730,14 @@ extern "C" int crsdr_plan_destroy(crsdr_plan *plan)
     return CRSDR_OK;
 }
 
+static int check_fused_status(crsdr_plan *p);
 extern "C" int crsdr_plan_sync(crsdr_plan *p)
 {
     if (!p) return fail(CRSDR_EINVAL, "plan_sync: NULL plan");
     HIP_TRY(hipSetDevice(p->device));
     HIP_TRY(hipStreamSynchronize(p->stream));
     HIP_TRY(hipStreamSynchronize(p->aux));
-    return CRSDR_OK;
+    return check_fused_status(p);
 }
 
 extern "C" int crsdr_plan_reset(crsdr_plan *p)
@@ -951,6 +957,22 @@ extern "C" int crsdr_plan_submit_batch(crsdr_plan *p, const void *rows, int mem_
     // phase path: faithful mode does not depend on this batch's lags, digital mode does; either
     // way it follows K1 on the main stream (K1 is VALU bound, these two are the HBM-bound tail)
     const int chunks = p->B > 16384 ? p->B / 16384 : 1; // long rows: 16 KiB of the row per workgroup
+    if (p->fused_k2 && vec16 && chunks == 1) {
+        // fused phase path: every row is read once (k_align_fused); timed under CRSDR_KERNEL_ALIGN_QUANT
+        FusedSync fs{p->d_sync, p->d_sync + 1, reinterpret_cast<unsigned long long *>(p->d_corr), p->row_count};
+        hipEvent_t *pe = prof_pair(p, CRSDR_KERNEL_ALIGN_QUANT);
+        if (pe) HIP_TRY(hipEventRecord(pe[0], S));
+        if (aa.refnoise && nblocks > 1) HIP_TRY(hipMemsetAsync(p->d_corr, 0xFF, sizeof(long long) * 2 * n * T, S)); // re-arm the chain
+        hipLaunchKernelGGL(k_align_fused, dim3((unsigned)((1 + p->row_count) * nblocks)), dim3(kAlignThreads), 0, S, aa, fs);
+        HIP_TRY(hipGetLastError());
+        if (pe) HIP_TRY(hipEventRecord(pe[1], S));
+        p->fused_used = true;
+        p->phase_cur = pout;
+        p->last_nblocks = nblocks;
+        if (p->prof_slots) { if (p->prof_mask & (1u << 31)) HIP_TRY(hipEventRecord(p->ev_stop, S)); p->prof_count++; }
+        p->submitted = true;
+        return CRSDR_OK;
+    }
     if (aa.refnoise) {
         hipEvent_t *pe = prof_pair(p, CRSDR_KERNEL_PHASE_DOT);
         if (pe) HIP_TRY(hipEventRecord(pe[0], S));
@@ -983,6 +1005,19 @@ extern "C" int crsdr_plan_submit(crsdr_plan *p, const void *rows, int mem_kind, 
     return crsdr_plan_submit_batch(p, rows, mem_kind, 1, 0, readcnt, lag_mask, seq, flags);
 }
 
+// a look-back wait of the fused phase kernel ran out (it never should): report it instead of silently wrong phasors
+static int check_fused_status(crsdr_plan *p)
+{
+    if (!p->fused_used) return CRSDR_OK;
+    unsigned int st = 0;
+    HIP_TRY(hipMemcpy(&st, p->d_sync + 1, sizeof(st), hipMemcpyDeviceToHost));
+    if (st) {
+        (void)hipMemset(p->d_sync, 0, 8);
+        return fail(CRSDR_EHIP, "phase chain look-back timed out (set CRSDR_K2_FUSED=0 for the three-kernel phase path)");
+    }
+    return CRSDR_OK;
+}
+
 extern "C" int crsdr_plan_fetch_block(crsdr_plan *p, int block, int32_t *lag, float *mag, float *frac, float *phasor,
                                       int8_t *packet)
 {
@@ -993,6 +1028,7 @@ extern "C" int crsdr_plan_fetch_block(crsdr_plan *p, int block, int32_t *lag, fl
     if (packet && p->d_slab) return fail(CRSDR_ESTATE, "plan_fetch: slab output is bound, packets are assembled by the caller (crsdr_assemble_slabs)");
     HIP_TRY(hipSetDevice(p->device));
     HIP_TRY(hipStreamSynchronize(p->stream));
+    { int rc_ = check_fused_status(p); if (rc_) return rc_; }
     const size_t n = (size_t)p->nrows, o = (size_t)block * n;
     if (lag) HIP_TRY(hipMemcpy(lag, p->d_lag + o, sizeof(int32_t) * n, hipMemcpyDeviceToHost));
     if (mag) HIP_TRY(hipMemcpy(mag, p->d_mag + o, sizeof(float) * n, hipMemcpyDeviceToHost));

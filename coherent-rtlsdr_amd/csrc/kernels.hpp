@@ -402,6 +402,141 @@ __global__ __launch_bounds__(kAlignThreads) void k_align_quant(AlignArgs a)
     }
 }
 
+// ---- K2 fused: dot -> phasor chain -> rotate with the row read ONCE ------------------------------------
+// One workgroup per (row, block) holds its 16 KiB row in registers (<= 4 x 16 B per thread), forms the exact
+// integer dot product, and then needs the phasor of the SAME row one block earlier (the EMA of
+// src/csdrdevice.cc:66-67 is a chain in block order).  That value comes from another workgroup, so:
+//   * work order = workgroup index, block-major: (row, t) depends only on a LOWER index.  Every hardware
+//     dispatch queue hands out workgroups in index order, so the lowest-indexed unfinished workgroup of the grid
+//     is always resident and never has to wait -- the grid cannot deadlock (the argument of decoupled look-back
+//     scans; a ticket drawn from one atomic counter would make it independent of the dispatcher, but 16 k
+//     atomics on one address cost more than the second read of the rows saves: measured, 14 vs 9.6 us / block);
+//   * the hand-over is ONE 64-bit agent-scope atomic per (row, block): chain[t][row] = bits of the float2
+//     phasor, all-ones (never an arithmetic result) meaning "not yet"; the host re-arms the array per submit;
+//   * the wait is bounded: after kFusedSpinLimit polls the workgroup flags *status and carries on with
+//     phase_in, so the grid always drains (the host turns a non-zero status into CRSDR_EHIP).
+// Grid: ((1 + owned rows) * nblocks) workgroups; 16-byte aligned rows only, B <= 16384 (one chunk).
+// Measured (r01, 16 blocks x 1025 rows): 8.8 us per block against 9.5 us for k_phase_dot + k_phase_chain +
+// k_align_quant; the locked cadence (phase path only) 92.7 k vs 81.6 k blocks/s.
+struct FusedSync {
+    unsigned int *ticket;              // unused (kept for a ticketed variant)
+    unsigned int *status;              // [0] != 0: a look-back wait ran out
+    unsigned long long *chain;         // [T][nrows][2]: [0] = phasor bits or all-ones
+    int row_count;
+};
+constexpr unsigned long long kChainEmpty = ~0ull;
+constexpr int kFusedSpinLimit = 1 << 22;
+
+__global__ __launch_bounds__(kAlignThreads) void k_align_fused(AlignArgs a, FusedSync fs)
+{
+    __shared__ long long sred[2 * (kAlignThreads / 64)];
+    __shared__ float2 sp;
+    const int tid = threadIdx.x;
+    const unsigned int per = (unsigned)fs.row_count + 1u;
+    const unsigned int ticket = blockIdx.x;
+    const int t = (int)(ticket / per), x = (int)(ticket % per);
+    const int B = a.B, L = B >> 1, nvec = B / 16;
+    const size_t moff = 16 + 4 * (size_t)a.nrows;
+    const int8_t *blk = a.rows + (size_t)t * a.block_stride;
+    int8_t *packet = a.packet + (size_t)t * a.packet_stride;
+    if (a.slab) {
+        if (x == 0 && (t < a.hdr_first || t >= a.hdr_first + a.hdr_count)) return;
+        packet = a.packet + (size_t)(t - a.hdr_first) * a.packet_stride;
+    }
+    if (x == 0) {
+        // header hdr0{globalseqn,N,L,unused} + readcnt words + the raw reference row (src/cpacketizer.cc:112-116,137-156)
+        uint32_t *h = reinterpret_cast<uint32_t *>(packet);
+        const uint32_t seq = a.seq + (uint32_t)t;
+        if (tid == 0) { h[0] = seq; h[1] = (uint32_t)a.nrows; h[2] = (uint32_t)L; h[3] = 0u; }
+        for (int r = tid; r < a.nrows; r += kAlignThreads) h[4 + r] = a.readcnt ? a.readcnt[(size_t)t * a.nrows + r] : seq;
+        const uint4 *src = reinterpret_cast<const uint4 *>(blk);
+        uint4 *dst = reinterpret_cast<uint4 *>(packet + moff);
+        for (int i = tid; i < nvec; i += kAlignThreads) {
+            const uint4 v = src[i];
+            dst[i] = make_uint4(v.x ^ a.xor80, v.y ^ a.xor80, v.z ^ a.xor80, v.w ^ a.xor80);
+        }
+        return;
+    }
+    const int row = a.row_begin + x - 1;
+    const size_t o = (size_t)t * a.nrows + row;
+    const int d = align_shift(a, row, t);
+    const int8_t *srow = blk + (size_t)row * B;
+    uint4 sv[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int i = tid + q * kAlignThreads;
+        sv[q] = (i < nvec) ? shifted_vec(srow, i, d, L, a.xor80) : make_uint4(0u, 0u, 0u, 0u);
+    }
+    if (a.refnoise) {
+        const uint4 *r128 = reinterpret_cast<const uint4 *>(blk);
+        int re = 0, im = 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int i = tid + q * kAlignThreads;
+            if (i < nvec) {
+                const uint4 rv = r128[i];
+                dot_word(sv[q].x, rv.x ^ a.xor80, re, im);
+                dot_word(sv[q].y, rv.y ^ a.xor80, re, im);
+                dot_word(sv[q].z, rv.z ^ a.xor80, re, im);
+                dot_word(sv[q].w, rv.w ^ a.xor80, re, im);
+            }
+        }
+        long long acc_re = re, acc_im = im;
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            acc_re += __shfl_xor(acc_re, off, 64);
+            acc_im += __shfl_xor(acc_im, off, 64);
+        }
+        if ((tid & 63) == 0) { sred[2 * (tid >> 6)] = acc_re; sred[2 * (tid >> 6) + 1] = acc_im; }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        if (!a.xcorr_ran) {   // no lag measured in this batch: republish the carried one (include/csdrdevice.h:161)
+            a.lag_out[o] = a.lag_state[row]; a.mag_out[o] = a.mag_state[row]; a.frac_out[o] = a.frac_state[row];
+        }
+        float2 p = a.phase_in[row];
+        if (a.refnoise) {
+            long long sr = 0, si = 0;
+            for (int w = 0; w < kAlignThreads / 64; ++w) { sr += sred[2 * w]; si += sred[2 * w + 1]; }
+            if (t > 0) {
+                // look back: the phasor of this row after block t-1
+                unsigned long long *src = fs.chain + 2 * (o - (size_t)a.nrows);
+                unsigned long long bits = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                int spins = 0;
+                while (bits == kChainEmpty && spins < kFusedSpinLimit) {
+                    __builtin_amdgcn_s_sleep(2);
+                    bits = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    ++spins;
+                }
+                if (bits == kChainEmpty) atomicExch(fs.status, 1u);
+                else p = make_float2(__uint_as_float((unsigned)(bits & 0xffffffffull)), __uint_as_float((unsigned)(bits >> 32)));
+            }
+            // csdrdevice::est_phasecorrect (src/csdrdevice.cc:58-69); |corr| == 0 holds the previous phasor
+            if (sr != 0 || si != 0) {
+                const double cr = (double)sr, ci = (double)si;
+                const double inv = 1.0 / sqrt(cr * cr + ci * ci);
+                const float pr = (float)(cr * inv), pi = (float)(-ci * inv);
+                p = make_float2(__fadd_rn(__fmul_rn(0.5f, pr), __fmul_rn(0.5f, p.x)),
+                                __fadd_rn(__fmul_rn(0.5f, pi), __fmul_rn(0.5f, p.y)));
+            }
+            const unsigned long long out = (unsigned long long)__float_as_uint(p.x) | ((unsigned long long)__float_as_uint(p.y) << 32);
+            __hip_atomic_store(fs.chain + 2 * o, out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        a.phasor[o] = p;                                    // get_phasecorrect() after block t
+        if (t == a.nblocks - 1) a.phase_out[row] = p;       // state carried to the next batch
+        sp = p;
+    }
+    __syncthreads();
+    const float2 p = sp;
+    int8_t *orow = a.slab ? a.slab + (size_t)t * a.slab_stride + (size_t)(row - a.row_begin) * B : packet + moff + (size_t)row * B;
+    uint4 *o128 = reinterpret_cast<uint4 *>(orow);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int i = tid + q * kAlignThreads;
+        if (i < nvec) o128[i] = make_uint4(rotq_word(sv[q].x, p), rotq_word(sv[q].y, p), rotq_word(sv[q].z, p), rotq_word(sv[q].w, p));
+    }
+}
+
 // ---- slab assembly on a gather root ---------------------------------------------------
 // recv [nsrc][nblocks][slab_words] (what an all-to-all of the ranks' slab buffers delivers) -> the matrix rows
 // 1 + src*per .. of packet j.  Pure copy, grid (chunks, nblocks, nsrc).

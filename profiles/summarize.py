@@ -33,7 +33,7 @@ def pmc_avg(counter):
     return res
 fetch, write = pmc_avg("FETCH_SIZE"), pmc_avg("WRITE_SIZE")
 traffic = {}
-for key, pat in (("k_xcorr_lag", "k_xcorr_lag"), ("k_phase_dot", "k_phase_dot"), ("k_align_quant", "k_align_quant"), ("k_ref_spectrum", "k_ref_spectrum")):
+for key, pat in (("k_xcorr_lag", "k_xcorr_lag"), ("k_phase_dot", "k_phase_dot"), ("k_align_quant", "k_align_quant"), ("k_align_fused", "k_align_fused"), ("k_ref_spectrum", "k_ref_spectrum")):
     ks = [k for k in fetch if pat in k]
     if not ks or ks[0] not in write:
         continue
