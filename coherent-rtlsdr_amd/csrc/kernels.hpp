@@ -411,10 +411,13 @@ __global__ __launch_bounds__(kAlignThreads) void k_align_quant(AlignArgs a)
 //     is always resident and never has to wait -- the grid cannot deadlock (the argument of decoupled look-back
 //     scans; a ticket drawn from one atomic counter would make it independent of the dispatcher, but 16 k
 //     atomics on one address cost more than the second read of the rows saves: measured, 14 vs 9.6 us / block);
-//   * the hand-over is ONE 64-bit agent-scope atomic per (row, block): chain[t][row] = bits of the float2
-//     phasor, all-ones (never an arithmetic result) meaning "not yet"; the host re-arms the array per submit;
-//   * the wait is bounded: after kFusedSpinLimit polls the workgroup flags *status and carries on with
-//     phase_in, so the grid always drains (the host turns a non-zero status into CRSDR_EHIP).
+//   * what is handed over is not the chain value but each block's own UNIT phasor (one 64-bit agent-scope atomic
+//     per (row, block), published right after the dot product; all-ones = "not yet", 0 = "|corr| = 0, hold");
+//     workgroup (row, t) fetches the t earlier ones with one load per lane and folds the EMA itself, in block
+//     order, from phase_in -- the same operations in the same order as a sequential chain, but nobody waits
+//     for anybody's rotation, only for dot products that started a thousand workgroups earlier;
+//   * the wait is bounded: after kFusedSpinLimit polls the workgroup flags *status and treats the block as
+//     "hold", so the grid always drains (the host turns a non-zero status into CRSDR_EHIP).
 // Grid: ((1 + owned rows) * nblocks) workgroups; 16-byte aligned rows only, B <= 16384 (one chunk).
 // Measured (r01, 16 blocks x 1025 rows): 8.8 us per block against 9.5 us for k_phase_dot + k_phase_chain +
 // k_align_quant; the locked cadence (phase path only) 92.7 k vs 81.6 k blocks/s.
@@ -490,41 +493,56 @@ __global__ __launch_bounds__(kAlignThreads) void k_align_fused(AlignArgs a, Fuse
         if ((tid & 63) == 0) { sred[2 * (tid >> 6)] = acc_re; sred[2 * (tid >> 6) + 1] = acc_im; }
     }
     __syncthreads();
-    if (tid == 0) {
-        if (!a.xcorr_ran) {   // no lag measured in this batch: republish the carried one (include/csdrdevice.h:161)
+    if (tid < 64) {
+        // wave 0: publish this block's unit phasor, then fold the chain over blocks 0..t of this row
+        if (tid == 0 && !a.xcorr_ran) {   // no lag measured in this batch: republish the carried one (include/csdrdevice.h:161)
             a.lag_out[o] = a.lag_state[row]; a.mag_out[o] = a.mag_state[row]; a.frac_out[o] = a.frac_state[row];
         }
         float2 p = a.phase_in[row];
         if (a.refnoise) {
-            long long sr = 0, si = 0;
-            for (int w = 0; w < kAlignThreads / 64; ++w) { sr += sred[2 * w]; si += sred[2 * w + 1]; }
-            if (t > 0) {
-                // look back: the phasor of this row after block t-1
-                unsigned long long *src = fs.chain + 2 * (o - (size_t)a.nrows);
-                unsigned long long bits = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            // csdrdevice::est_phasecorrect (src/csdrdevice.cc:58-69): unit phasor conj(corr)/|corr| of THIS block;
+            // 0 = "|corr| == 0, hold the previous phasor" (a unit phasor is never 0)
+            unsigned long long mine = 0ull;
+            if (tid == 0) {
+                long long sr = 0, si = 0;
+                for (int w = 0; w < kAlignThreads / 64; ++w) { sr += sred[2 * w]; si += sred[2 * w + 1]; }
+                if (sr != 0 || si != 0) {
+                    const double cr = (double)sr, ci = (double)si;
+                    const double inv = 1.0 / sqrt(cr * cr + ci * ci);
+                    mine = (unsigned long long)__float_as_uint((float)(cr * inv)) | ((unsigned long long)__float_as_uint((float)(-ci * inv)) << 32);
+                }
+                __hip_atomic_store(fs.chain + 2 * o, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            // lane u < t fetches the unit phasor of block u (published right after that block's dot product, long
+            // before its own rotation), lane t takes this block's; then one sequential fold in block order
+            unsigned long long bits = 0ull;
+            if (tid < t) {
+                unsigned long long *src = fs.chain + 2 * ((size_t)tid * a.nrows + row);
+                bits = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 int spins = 0;
                 while (bits == kChainEmpty && spins < kFusedSpinLimit) {
                     __builtin_amdgcn_s_sleep(2);
                     bits = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     ++spins;
                 }
-                if (bits == kChainEmpty) atomicExch(fs.status, 1u);
-                else p = make_float2(__uint_as_float((unsigned)(bits & 0xffffffffull)), __uint_as_float((unsigned)(bits >> 32)));
+                if (bits == kChainEmpty) { atomicExch(fs.status, 1u); bits = 0ull; }
             }
-            // csdrdevice::est_phasecorrect (src/csdrdevice.cc:58-69); |corr| == 0 holds the previous phasor
-            if (sr != 0 || si != 0) {
-                const double cr = (double)sr, ci = (double)si;
-                const double inv = 1.0 / sqrt(cr * cr + ci * ci);
-                const float pr = (float)(cr * inv), pi = (float)(-ci * inv);
-                p = make_float2(__fadd_rn(__fmul_rn(0.5f, pr), __fmul_rn(0.5f, p.x)),
-                                __fadd_rn(__fmul_rn(0.5f, pi), __fmul_rn(0.5f, p.y)));
+            const unsigned long long own = __shfl(mine, 0, 64);
+            if (tid == t) bits = own;
+            for (int u = 0; u <= t; ++u) {
+                const unsigned long long b = __shfl(bits, u, 64);
+                if (b != 0ull) {
+                    const float pr = __uint_as_float((unsigned)(b & 0xffffffffull)), pi = __uint_as_float((unsigned)(b >> 32));
+                    p = make_float2(__fadd_rn(__fmul_rn(0.5f, pr), __fmul_rn(0.5f, p.x)),
+                                    __fadd_rn(__fmul_rn(0.5f, pi), __fmul_rn(0.5f, p.y)));
+                }
             }
-            const unsigned long long out = (unsigned long long)__float_as_uint(p.x) | ((unsigned long long)__float_as_uint(p.y) << 32);
-            __hip_atomic_store(fs.chain + 2 * o, out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-        a.phasor[o] = p;                                    // get_phasecorrect() after block t
-        if (t == a.nblocks - 1) a.phase_out[row] = p;       // state carried to the next batch
-        sp = p;
+        if (tid == 0) {
+            a.phasor[o] = p;                                    // get_phasecorrect() after block t
+            if (t == a.nblocks - 1) a.phase_out[row] = p;       // state carried to the next batch
+            sp = p;
+        }
     }
     __syncthreads();
     const float2 p = sp;
