@@ -168,10 +168,13 @@ def main():
             run_batch(ib, nb, fl)
             ib, left = ib + 1, left - nb
 
+    host_issue = {}
+
     def timed(nsteps, fl=flags):
         fence()
         t0 = time.perf_counter()
         run_steps(nsteps, fl)
+        host_issue["s"] = time.perf_counter() - t0       # host time to enqueue everything (no waiting on the GPU)
         fence()
         dt = time.perf_counter() - t0
         if world > 1:
@@ -194,6 +197,7 @@ def main():
     # timed region: hipEvent pairs around the dominant kernel (K1) only -- every pair costs stream time
     plan.enable_profiling(min(max(args.steps, 1), 1024), 1 << b.KERNEL_XCORR_LAG)
     dt = timed(args.steps)
+    host_ms_per_batch = 1e3 * host_issue["s"] / max(1, -(-args.steps // T))
     k_ms = {"xcorr_lag": plan.kernel_times_ms(b.KERNEL_XCORR_LAG)}
     # the other kernels: a short untimed loop with every pair recorded
     plan.enable_profiling(64, 0xF)
@@ -256,6 +260,7 @@ def main():
             "whole_path": {"algorithmic_bytes_per_block": A_block,
                            "hbm_read_frac": A_block * blocks_per_s / (world * HBM_PEAK_GBS * 1e9)},
             "kernel_ms": {k: (float(np.mean(v)) if len(v) else None) for k, v in k_ms.items()},
+            "host_issue_ms_per_batch": host_ms_per_batch,
             "lags_exact": lags_ok, "matrix_assembled": assembled_ok if world > 1 else None,
             "env": _env(torch, dev, b, local_rank),
         }
