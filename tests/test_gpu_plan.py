@@ -519,3 +519,22 @@ def test_half_row_k1_variant_matches_the_default_kernel(tmp_path):
     assert np.allclose(h["frac"], f["frac"], atol=1e-3)
     d = h["packet"].astype(np.int16) - f["packet"].astype(np.int16)
     assert np.abs(d).max() <= 1 and np.count_nonzero(d) <= 1e-4 * d.size
+
+
+def test_plan_lifecycle_does_not_leak_device_memory(b, synth):
+    # create / submit / destroy in a loop (all three kernel families: generic, 16384, long-block): device memory
+    # in use returns to where it started (the plan owns every device allocation, src/ccoherent.cc:100-110)
+    import torch
+    rows = {B: synth.make_block(2, B // 2, 3, 0, dmax=4)[0] for B in (1024, 16384, 1 << 15)}
+    for B in rows:                                   # warm the allocator / code objects first
+        b.Plan(3, B, b.MODE_DIGITAL).block(rows[B])
+    torch.cuda.synchronize()
+    free0, _ = torch.cuda.mem_get_info()
+    for _ in range(40):
+        for B in rows:
+            p = b.Plan(3, B, b.MODE_DIGITAL, max_batch=1 if B > 16384 else 4)
+            p.block(rows[B])
+            p.close()
+    torch.cuda.synchronize()
+    free1, _ = torch.cuda.mem_get_info()
+    assert abs(free0 - free1) <= 8 << 20, (free0, free1)
