@@ -22,36 +22,42 @@ struct hdr0 { // include/cpacketizer.h:32-37
 };
 
 class cpacketize {
-    static int objcount;
-    static std::mutex bmutex;
-    static std::condition_variable cv;
-    static bool noheader;
-    static size_t packetlen;
-    static uint32_t globalseqn;
-    static bool bufferfilled;
-    static bool do_exit;
-    static uint32_t blocksize;
-    static std::unique_ptr<int8_t[]> packetbuf0, packetbuf1; // one being sent, one written to
-    static std::vector<std::complex<float>> pcorrection;
-    static void resize_buffers(uint32_t N, uint32_t L);
 public:
     typedef std::function<void(const int8_t *packet, size_t bytes, const std::complex<float> *phase, size_t n)> sink_t;
-    static sink_t sink;
-    static std::string debugaddress;   // reference: "tcp://*:5557" (src/cpacketizer.cc:66); set before init()
-    static bool publishing();          // true when the ZMQ PUB sockets are bound
-    // packet bytes for N channels of blocksize L: (16 + 4N) + N*L.  The reference allocates and
-    // sends 2*N*L data bytes (src/cpacketizer.cc:95), of which clients read N*L
-    // (matlabclient/zmqsdr.c:121-143); the tail padding is not reproduced.
-    static size_t packetlength(uint32_t N, uint32_t L);
+
     cpacketize();
     ~cpacketize();
+
+    // -- process-wide set-up (src/main.cc:261 calls init once; src/cpacketizer.cc:58-96)
     static void init(std::string address, bool noheader_, uint32_t nchannels_, uint32_t blocksize_);
     static void cleanup();
-    void request_exit();
-    static int send();
-    int write(uint32_t channeln, uint32_t readcnt, int8_t *rp);
-    int write(uint32_t channeln, uint32_t readcnt, std::complex<float> *in);
+    static std::string debugaddress;   // reference: "tcp://*:5557" (src/cpacketizer.cc:66); set before init()
+    static sink_t sink;                // every sent packet also goes here (embedding / tests)
+    static bool publishing();          // true when the ZMQ PUB sockets are bound
+    // Packet bytes for N channels of blocksize L: (16 + 4N) + N*L.  The reference allocates and sends 2*N*L data
+    // bytes (src/cpacketizer.cc:95), of which clients read N*L (matlabclient/zmqsdr.c:121-143); the tail padding
+    // is not reproduced.
+    static size_t packetlength(uint32_t N, uint32_t L);
+
+    // -- per block, from the engine thread (src/ccoherent.cc:253,277-279,288; src/cpacketizer.cc:137-185)
+    int write(uint32_t channeln, uint32_t readcnt, int8_t *rp);                 // a row that is already int8
+    int write(uint32_t channeln, uint32_t readcnt, std::complex<float> *in);    // convto8bit on the way in
     int writedebug(uint32_t channeln, std::complex<float> p);
     int notifysend();
+    void request_exit();
+
+    // -- publish loop, main thread (src/main.cc:277-279; src/cpacketizer.cc:109-129)
+    static int send();
+
+private:
+    static void resize_buffers(uint32_t N, uint32_t L);
+    static std::unique_ptr<int8_t[]> packetbuf0, packetbuf1;   // one being sent, one written to
+    static std::vector<std::complex<float>> pcorrection;       // debug side channel: N phase factors
+    static std::mutex bmutex;
+    static std::condition_variable cv;
+    static size_t packetlen;
+    static uint32_t globalseqn, blocksize;
+    static bool noheader, bufferfilled, do_exit;
+    static int objcount;
 };
 #endif
