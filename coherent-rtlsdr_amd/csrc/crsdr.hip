@@ -1005,16 +1005,15 @@ extern "C" int crsdr_plan_submit(crsdr_plan *p, const void *rows, int mem_kind, 
     return crsdr_plan_submit_batch(p, rows, mem_kind, 1, 0, readcnt, lag_mask, seq, flags);
 }
 
-// a look-back wait of the fused phase kernel ran out (it never should): report it instead of silently wrong phasors
+// the fused phase kernel counts look-back waits it gave up on (and computed locally): nothing to report, results are
+// exact either way; the counter is only kept for diagnostics (CRSDR_K2_DEBUG=1 prints it)
 static int check_fused_status(crsdr_plan *p)
 {
-    if (!p->fused_used) return CRSDR_OK;
+    static const bool dbg = [] { const char *e = getenv("CRSDR_K2_DEBUG"); return e && atoi(e) != 0; }();
+    if (!p->fused_used || !dbg) return CRSDR_OK;
     unsigned int st = 0;
     HIP_TRY(hipMemcpy(&st, p->d_sync + 1, sizeof(st), hipMemcpyDeviceToHost));
-    if (st) {
-        (void)hipMemset(p->d_sync, 0, 8);
-        return fail(CRSDR_EHIP, "phase chain look-back timed out (set CRSDR_K2_FUSED=0 for the three-kernel phase path)");
-    }
+    if (st) { std::fprintf(stderr, "crsdr: fused phase kernel computed %u look-back values locally\n", st); (void)hipMemset(p->d_sync, 0, 8); }
     return CRSDR_OK;
 }
 

@@ -416,24 +416,28 @@ __global__ __launch_bounds__(kAlignThreads) void k_align_quant(AlignArgs a)
 //     workgroup (row, t) fetches the t earlier ones with one load per lane and folds the EMA itself, in block
 //     order, from phase_in -- the same operations in the same order as a sequential chain, but nobody waits
 //     for anybody's rotation, only for dot products that started a thousand workgroups earlier;
-//   * the wait is bounded: after kFusedSpinLimit polls the workgroup flags *status and treats the block as
-//     "hold", so the grid always drains (the host turns a non-zero status into CRSDR_EHIP).
+//   * the wait is bounded and nothing depends on it: after kFusedSpinLimit polls a workgroup forms the missing
+//     block's dot product itself (same integers, same phasor), so the kernel terminates and stays exact under any
+//     scheduling -- e.g. when another process shares the GPU and this grid's dispatch is paused while its resident
+//     waves drain, which is where waiting workgroups would otherwise sit on predecessors that cannot start.
+//     *status counts how often that happened (0 in every run on an exclusive GPU).
 // Grid: ((1 + owned rows) * nblocks) workgroups; 16-byte aligned rows only, B <= 16384 (one chunk).
 // Measured (r01, 16 blocks x 1025 rows): 8.8 us per block against 9.5 us for k_phase_dot + k_phase_chain +
 // k_align_quant; the locked cadence (phase path only) 92.7 k vs 81.6 k blocks/s.
 struct FusedSync {
     unsigned int *ticket;              // unused (kept for a ticketed variant)
-    unsigned int *status;              // [0] != 0: a look-back wait ran out
+    unsigned int *status;              // [0] number of look-back waits that ran out and were computed locally
     unsigned long long *chain;         // [T][nrows][2]: [0] = phasor bits or all-ones
     int row_count;
 };
 constexpr unsigned long long kChainEmpty = ~0ull;
-constexpr int kFusedSpinLimit = 1 << 22;
+constexpr int kFusedSpinLimit = 2048;      // polls of ~1 us each before a workgroup stops waiting and computes the value itself
 
-__global__ __launch_bounds__(kAlignThreads) void k_align_fused(AlignArgs a, FusedSync fs)
+__global__ __launch_bounds__(kAlignThreads, 8) void k_align_fused(AlignArgs a, FusedSync fs)
 {
     __shared__ long long sred[2 * (kAlignThreads / 64)];
     __shared__ float2 sp;
+    __shared__ unsigned long long smiss, sfix[64];
     const int tid = threadIdx.x;
     const unsigned int per = (unsigned)fs.row_count + 1u;
     const unsigned int ticket = blockIdx.x;
@@ -493,43 +497,86 @@ __global__ __launch_bounds__(kAlignThreads) void k_align_fused(AlignArgs a, Fuse
         if ((tid & 63) == 0) { sred[2 * (tid >> 6)] = acc_re; sred[2 * (tid >> 6) + 1] = acc_im; }
     }
     __syncthreads();
+    // unit phasor conj(corr)/|corr| from the integer sums; 0 = "|corr| == 0, hold the previous phasor"
+    auto unit_bits = [](long long sr, long long si) -> unsigned long long {
+        if (sr == 0 && si == 0) return 0ull;
+        const double cr = (double)sr, ci = (double)si;
+        const double inv = 1.0 / sqrt(cr * cr + ci * ci);
+        return (unsigned long long)__float_as_uint((float)(cr * inv)) | ((unsigned long long)__float_as_uint((float)(-ci * inv)) << 32);
+    };
+    unsigned long long bits = 0ull;          // wave 0, lane u <= t: unit phasor of block u of this row
     if (tid < 64) {
-        // wave 0: publish this block's unit phasor, then fold the chain over blocks 0..t of this row
         if (tid == 0 && !a.xcorr_ran) {   // no lag measured in this batch: republish the carried one (include/csdrdevice.h:161)
             a.lag_out[o] = a.lag_state[row]; a.mag_out[o] = a.mag_state[row]; a.frac_out[o] = a.frac_state[row];
         }
-        float2 p = a.phase_in[row];
         if (a.refnoise) {
-            // csdrdevice::est_phasecorrect (src/csdrdevice.cc:58-69): unit phasor conj(corr)/|corr| of THIS block;
-            // 0 = "|corr| == 0, hold the previous phasor" (a unit phasor is never 0)
+            // csdrdevice::est_phasecorrect (src/csdrdevice.cc:58-69) for THIS block, published at once
             unsigned long long mine = 0ull;
             if (tid == 0) {
                 long long sr = 0, si = 0;
                 for (int w = 0; w < kAlignThreads / 64; ++w) { sr += sred[2 * w]; si += sred[2 * w + 1]; }
-                if (sr != 0 || si != 0) {
-                    const double cr = (double)sr, ci = (double)si;
-                    const double inv = 1.0 / sqrt(cr * cr + ci * ci);
-                    mine = (unsigned long long)__float_as_uint((float)(cr * inv)) | ((unsigned long long)__float_as_uint((float)(-ci * inv)) << 32);
-                }
+                mine = unit_bits(sr, si);
                 __hip_atomic_store(fs.chain + 2 * o, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
             // lane u < t fetches the unit phasor of block u (published right after that block's dot product, long
-            // before its own rotation), lane t takes this block's; then one sequential fold in block order
-            unsigned long long bits = 0ull;
+            // before its own rotation); lane t takes this block's
             if (tid < t) {
                 unsigned long long *src = fs.chain + 2 * ((size_t)tid * a.nrows + row);
                 bits = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 int spins = 0;
                 while (bits == kChainEmpty && spins < kFusedSpinLimit) {
-                    __builtin_amdgcn_s_sleep(2);
+                    __builtin_amdgcn_s_sleep(8);
                     bits = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     ++spins;
                 }
-                if (bits == kChainEmpty) { atomicExch(fs.status, 1u); bits = 0ull; }
             }
             const unsigned long long own = __shfl(mine, 0, 64);
             if (tid == t) bits = own;
-            for (int u = 0; u <= t; ++u) {
+            const unsigned long long missing = __ballot(tid < t && bits == kChainEmpty);
+            if (tid == 0) smiss = missing;
+        } else if (tid == 0) smiss = 0ull;
+    }
+    __syncthreads();
+    // Fallback, normally never taken: an earlier block's workgroup has not published within the poll budget (its
+    // queue was descheduled, e.g. another process shares the GPU and dispatch of this grid is paused while its
+    // resident waves drain).  Nothing may depend on it then: the whole workgroup forms that block's dot product
+    // itself -- same integers, same unit phasor -- so the kernel terminates and stays exact under any scheduling.
+    for (unsigned long long miss = smiss; miss != 0ull; miss &= miss - 1ull) {
+        const int u = __builtin_ctzll(miss);
+        const int8_t *blku = a.rows + (size_t)u * a.block_stride;
+        const int du = align_shift(a, row, u);
+        const uint4 *r128 = reinterpret_cast<const uint4 *>(blku);
+        int re = 0, im = 0;
+        for (int i = tid; i < nvec; i += kAlignThreads) {
+            const uint4 s = shifted_vec(blku + (size_t)row * B, i, du, L, a.xor80);
+            const uint4 rv = r128[i];
+            dot_word(s.x, rv.x ^ a.xor80, re, im);
+            dot_word(s.y, rv.y ^ a.xor80, re, im);
+            dot_word(s.z, rv.z ^ a.xor80, re, im);
+            dot_word(s.w, rv.w ^ a.xor80, re, im);
+        }
+        long long acc_re = re, acc_im = im;
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            acc_re += __shfl_xor(acc_re, off, 64);
+            acc_im += __shfl_xor(acc_im, off, 64);
+        }
+        __syncthreads();                       // sred / sfix of the previous round are consumed
+        if ((tid & 63) == 0) { sred[2 * (tid >> 6)] = acc_re; sred[2 * (tid >> 6) + 1] = acc_im; }
+        __syncthreads();
+        if (tid == 0) {
+            long long sr = 0, si = 0;
+            for (int w = 0; w < kAlignThreads / 64; ++w) { sr += sred[2 * w]; si += sred[2 * w + 1]; }
+            sfix[u] = unit_bits(sr, si);
+            atomicAdd(fs.status, 1u);          // counted, not an error: how often the fallback ran
+        }
+        __syncthreads();
+    }
+    if (tid < 64) {
+        float2 p = a.phase_in[row];
+        if (a.refnoise) {
+            if (tid < t && bits == kChainEmpty) bits = sfix[tid];
+            for (int u = 0; u <= t; ++u) {     // one sequential fold in block order (src/csdrdevice.cc:66-67)
                 const unsigned long long b = __shfl(bits, u, 64);
                 if (b != 0ull) {
                     const float pr = __uint_as_float((unsigned)(b & 0xffffffffull)), pi = __uint_as_float((unsigned)(b >> 32));
