@@ -959,7 +959,8 @@ extern "C" int crsdr_plan_submit_batch(crsdr_plan *p, const void *rows, int mem_
     const int chunks = p->B > 16384 ? p->B / 16384 : 1; // long rows: 16 KiB of the row per workgroup
     if (p->fused_k2 && vec16 && chunks == 1) {
         // fused phase path: every row is read once (k_align_fused); timed under CRSDR_KERNEL_ALIGN_QUANT
-        FusedSync fs{p->d_sync, p->d_sync + 1, reinterpret_cast<unsigned long long *>(p->d_corr), p->row_count};
+        static const int spin_limit = [] { const char *e = getenv("CRSDR_K2_SPIN"); return e ? atoi(e) : kFusedSpinLimit; }();
+        FusedSync fs{p->d_sync, p->d_sync + 1, reinterpret_cast<unsigned long long *>(p->d_corr), p->row_count, spin_limit};
         hipEvent_t *pe = prof_pair(p, CRSDR_KERNEL_ALIGN_QUANT);
         if (pe) HIP_TRY(hipEventRecord(pe[0], S));
         if (aa.refnoise && nblocks > 1) HIP_TRY(hipMemsetAsync(p->d_corr, 0xFF, sizeof(long long) * 2 * n * T, S)); // re-arm the chain

@@ -429,6 +429,7 @@ struct FusedSync {
     unsigned int *status;              // [0] number of look-back waits that ran out and were computed locally
     unsigned long long *chain;         // [T][nrows][2]: [0] = phasor bits or all-ones
     int row_count;
+    int spin_limit;                    // polls before the local fallback (kFusedSpinLimit; tests force 0)
 };
 constexpr unsigned long long kChainEmpty = ~0ull;
 constexpr int kFusedSpinLimit = 2048;      // polls of ~1 us each before a workgroup stops waiting and computes the value itself
@@ -524,7 +525,7 @@ __global__ __launch_bounds__(kAlignThreads, 8) void k_align_fused(AlignArgs a, F
                 unsigned long long *src = fs.chain + 2 * ((size_t)tid * a.nrows + row);
                 bits = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 int spins = 0;
-                while (bits == kChainEmpty && spins < kFusedSpinLimit) {
+                while (bits == kChainEmpty && spins < fs.spin_limit) {
                     __builtin_amdgcn_s_sleep(8);
                     bits = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     ++spins;

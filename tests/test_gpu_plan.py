@@ -538,3 +538,39 @@ def test_plan_lifecycle_does_not_leak_device_memory(b, synth):
     torch.cuda.synchronize()
     free1, _ = torch.cuda.mem_get_info()
     assert abs(free0 - free1) <= 8 << 20, (free0, free1)
+
+
+def test_phase_path_variants_are_bit_identical(tmp_path):
+    # the fused phase kernel (default), the same kernel with its look-back budget forced to zero -- every phasor
+    # of an earlier block that is not there yet is recomputed by the waiting workgroup itself -- and the
+    # three-kernel path (CRSDR_K2_FUSED=0) must agree bit for bit: same integer sums, same EMA order
+    import subprocess, sys, textwrap
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = textwrap.dedent('''
+        import importlib, sys, numpy as np
+        sys.path.insert(0, %r)
+        pkg = importlib.import_module("coherent-rtlsdr_amd")
+        b, synth = pkg.binding, pkg.synth
+        nsig, L, T = 300, 8192, 8
+        params = synth.RowParams(nsig, L, 777, dmax=1500)
+        blocks = np.stack([synth.make_block(nsig, L, 777, t, params=params)[0] for t in range(T)])
+        blocks[3, 7] = 0                                  # a zero row in one block: "hold the previous phasor"
+        plan = b.Plan(nsig + 1, 2 * L, b.MODE_DIGITAL, max_batch=T)
+        res = []
+        for rep in range(2):                              # second batch: state carried across submits
+            plan.submit(blocks, seq=rep * T)
+            res += [plan.fetch(block=t) for t in range(T)]
+        plan.submit(blocks, seq=99, flags=b.REFNOISE_ENABLED | b.NO_LAG)     # locked cadence
+        res += [plan.fetch(block=t) for t in range(T)]
+        np.savez(sys.argv[1], phasor=np.stack([r["phasor"] for r in res]), packet=np.stack([r["packet"] for r in res]),
+                 lag=np.stack([r["lag"] for r in res]), mag=np.stack([r["mag"] for r in res]))
+    ''') % root
+    outs = {}
+    for name, env in (("fused", {}), ("fallback", {"CRSDR_K2_SPIN": "0"}), ("three", {"CRSDR_K2_FUSED": "0"})):
+        out = tmp_path / f"{name}.npz"
+        r = subprocess.run([sys.executable, "-c", code, str(out)], env=dict(os.environ, **env), capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stdout + r.stderr
+        outs[name] = np.load(out)
+    for other in ("fallback", "three"):
+        for key in ("phasor", "packet", "lag", "mag"):
+            assert np.array_equal(outs["fused"][key].view(np.uint8), outs[other][key].view(np.uint8)), (other, key)
