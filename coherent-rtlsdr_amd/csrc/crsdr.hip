@@ -191,8 +191,17 @@ static hipError_t launch_ref_spectrum14(hipStream_t s, int nblocks, const int8_t
 
 static hipError_t launch_xcorr_lag14(hipStream_t s, const XcorrArgs &a, int row_count, const float2 *twA, const float2 *twB)
 {
-    // CRSDR_K1_VARIANT: "half" = two rows per CU (xcorr14h.hpp), "full" = one 128 KiB row per CU (xcorr14.hpp)
-    static const bool half = [] { const char *v = getenv("CRSDR_K1_VARIANT"); return v ? (v[0] == 'h') : false; }();
+    // CRSDR_K1_VARIANT: "packed" (default) = xcorr14p.hpp, packed complex arithmetic; "scalar" = xcorr14.hpp, the same
+    // network on scalar fp32 ops (bit-identical results); "half" = xcorr14h.hpp, two rows per CU (experiment)
+    static const char variant = [] { const char *v = getenv("CRSDR_K1_VARIANT"); return v ? v[0] : 'p'; }();
+    const bool half = variant == 'h';
+    if (variant == 'p' || variant == 'k') {
+        auto kp = x14p::k_xcorr_lag14p;
+        hipError_t ep = hipFuncSetAttribute((const void *)kp, hipFuncAttributeMaxDynamicSharedMemorySize, x14::LDS_BYTES);
+        if (ep != hipSuccess) return ep;
+        hipLaunchKernelGGL(kp, dim3(row_count, a.nblocks), dim3(x14::THREADS), x14::LDS_BYTES, s, a, twA, twB);
+        return hipGetLastError();
+    }
     if (half) {
         auto kh = x14h::k_xcorr_lag14h;
         hipError_t eh = hipFuncSetAttribute((const void *)kh, hipFuncAttributeMaxDynamicSharedMemorySize, x14h::LDS_BYTES_H);

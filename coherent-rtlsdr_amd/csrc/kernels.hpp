@@ -23,6 +23,7 @@
 #include "plan_args.hpp"
 #include "xcorr14.hpp"
 #include "xcorr14h.hpp"
+#include "xcorr14p.hpp"
 #include "longblock.hpp"
 #include "covariance.hpp"
 #include "music.hpp"

@@ -486,8 +486,8 @@ def test_device_input_and_bound_packet_alignments(b, synth, B):
     ref.close()
 
 
-def test_half_row_k1_variant_matches_the_default_kernel(tmp_path):
-    # CRSDR_K1_VARIANT=half selects xcorr14h.hpp (two rows per CU, even / odd plane trips through 66 KiB of LDS).
+def test_k1_variants_agree(tmp_path):
+    # CRSDR_K1_VARIANT: packed (default, xcorr14p.hpp) must equal scalar (xcorr14.hpp) bit for bit; half selects xcorr14h.hpp (two rows per CU, even / odd plane trips through 66 KiB of LDS).
     # The variant is chosen once per process, so it runs in a child: same lags, mag within 1e-5 (the last pass is
     # decimation-in-time instead of -in-frequency), same packets except +-1 LSB at rounding boundaries.
     import subprocess, sys, textwrap
@@ -507,13 +507,16 @@ def test_half_row_k1_variant_matches_the_default_kernel(tmp_path):
                  frac=np.stack([o["frac"] for o in outs]), packet=np.stack([o["packet"] for o in outs]), d=params.d)
     ''') % root
     res = {}
-    for variant in ("full", "half"):
+    for variant in ("scalar", "half", "packed"):
         out = tmp_path / f"{variant}.npz"
         env = dict(os.environ, CRSDR_K1_VARIANT=variant)
         r = subprocess.run([sys.executable, "-c", code, str(out)], env=env, capture_output=True, text=True, timeout=300)
         assert r.returncode == 0, r.stdout + r.stderr
         res[variant] = np.load(out)
-    f, h = res["full"], res["half"]
+    # the packed kernel (default) rounds every operation like the scalar one: identical bits
+    for key in ("lag", "mag", "frac", "packet"):
+        assert np.array_equal(res["packed"][key].view(np.uint8), res["scalar"][key].view(np.uint8)), key
+    f, h = res["scalar"], res["half"]
     assert np.array_equal(h["lag"], f["lag"]) and np.array_equal(h["lag"][0, 1:], f["d"])
     assert np.allclose(h["mag"], f["mag"], rtol=1e-5)
     assert np.allclose(h["frac"], f["frac"], atol=1e-3)
