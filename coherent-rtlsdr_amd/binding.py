@@ -12,7 +12,7 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_SO = os.path.join(_HERE, "libcrsdr.so")
+_SO = os.environ.get("CRSDR_LIB") or os.path.join(_HERE, "libcrsdr.so")   # CRSDR_LIB: A/B a second build (diagnostics)
 ROOT = os.path.dirname(_HERE)
 
 MODE_FAITHFUL, MODE_DIGITAL = 0, 1

@@ -946,7 +946,7 @@ extern "C" int crsdr_plan_submit_batch(crsdr_plan *p, const void *rows, int mem_
         XcorrArgs xa;
         xa.rows = d_in; xa.block_stride = d_stride; xa.refspec = p->d_refspec[slot]; xa.lag_mask = d_mask;
         xa.row_begin = p->row_begin; xa.nrows = p->nrows; xa.nblocks = nblocks; xa.xor80 = xor80;
-        { const char *sg = getenv("CRSDR_K1_STAGGER"); xa.stagger = sg ? atoi(sg) : 1; } // x 512 cycles
+        { const char *sg = getenv("CRSDR_K1_STAGGER"); xa.stagger = sg ? atoi(sg) : 0; } // x 512 cycles; 0 is best for the packed kernel, 1 for the scalar one
         xa.lag = p->d_lag; xa.mag = p->d_mag; xa.frac = p->d_frac;
         xa.lag_state = p->d_lag_state; xa.mag_state = p->d_mag_state; xa.frac_state = p->d_frac_state;
         HIP_TRY(hipStreamWaitEvent(S, p->ev_ref[slot], 0));

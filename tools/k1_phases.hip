@@ -18,7 +18,7 @@ constexpr int NST = 9;
         if ((threadIdx.x & 63) == 0)                                                                     \
             g_stamps[((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 8 + (threadIdx.x >> 6)) * NST + (i)] = t_; \
     } while (0)
-#include "xcorr14.hpp"
+#include "xcorr14p.hpp"
 using namespace crsdr;
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
 int main()
@@ -42,12 +42,12 @@ int main()
     unsigned long long *stamps; CK(hipMalloc(&stamps, (size_t)nwg * 8 * NST * 8)); CK(hipMemset(stamps, 0, (size_t)nwg * 8 * NST * 8));
     CK(hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), &stamps, sizeof(stamps)));
     CK(hipFuncSetAttribute((const void *)x14::k_ref_spectrum14, hipFuncAttributeMaxDynamicSharedMemorySize, x14::LDS_BYTES));
-    CK(hipFuncSetAttribute((const void *)x14::k_xcorr_lag14, hipFuncAttributeMaxDynamicSharedMemorySize, x14::LDS_BYTES));
+    CK(hipFuncSetAttribute((const void *)x14p::k_xcorr_lag14p, hipFuncAttributeMaxDynamicSharedMemorySize, x14::LDS_BYTES));
     hipLaunchKernelGGL(x14::k_ref_spectrum14, dim3(T), dim3(512), x14::LDS_BYTES, 0, d_rows, (size_t)rows * N, twA, twB, (float4 *)refspec, 0u);
     XcorrArgs xa{};
     xa.rows = d_rows; xa.block_stride = (size_t)rows * N; xa.refspec = refspec; xa.lag_mask = nullptr; xa.row_begin = 1; xa.nrows = rows;
     xa.nblocks = T; xa.xor80 = 0; xa.lag = lag; xa.mag = mag; xa.frac = frac; xa.lag_state = lag_s; xa.mag_state = mag_s; xa.frac_state = frac_s;
-    for (int rep = 0; rep < 3; ++rep) hipLaunchKernelGGL(x14::k_xcorr_lag14, dim3(rows - 1, T), dim3(512), x14::LDS_BYTES, 0, xa, twA, twB);
+    for (int rep = 0; rep < 3; ++rep) hipLaunchKernelGGL(x14p::k_xcorr_lag14p, dim3(rows - 1, T), dim3(512), x14::LDS_BYTES, 0, xa, twA, twB);
     CK(hipDeviceSynchronize());
     std::vector<unsigned long long> st((size_t)nwg * 8 * NST);
     CK(hipMemcpy(st.data(), stamps, st.size() * 8, hipMemcpyDeviceToHost));
