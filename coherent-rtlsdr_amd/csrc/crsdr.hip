@@ -179,23 +179,37 @@ static hipError_t launch_xcorr_lag(hipStream_t s, const XcorrArgs &a, int row_co
     return hipGetLastError();
 }
 
+// CRSDR_K1_VARIANT: "packed" (default) = xcorr14p.hpp, packed complex arithmetic; "scalar" = xcorr14.hpp, the same network
+// on scalar fp32 ops (bit-identical results); "half" = xcorr14h.hpp for K1 only, two rows per CU (experiment, scalar K0)
+static char k1_variant()
+{
+    static const char v = [] { const char *e = getenv("CRSDR_K1_VARIANT"); return e ? e[0] : 'p'; }();
+    return v == 'k' ? 'p' : v;
+}
+
 static hipError_t launch_ref_spectrum14(hipStream_t s, int nblocks, const int8_t *rows, size_t block_stride, const float2 *twA,
                                         const float2 *twB, float2 *refspec, uint32_t xor80)
 {
-    auto kern = x14::k_ref_spectrum14;
+    if (k1_variant() == 's') {   // scalar arithmetic (xcorr14.hpp); the packed kernels give identical bits
+        auto kern = x14::k_ref_spectrum14;
+        hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, x14::LDS_BYTES);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(kern, dim3(nblocks), dim3(x14::THREADS), x14::LDS_BYTES, s, rows, block_stride, twA, twB, (float4 *)refspec, xor80);
+        return hipGetLastError();
+    }
+    auto kern = x14p::k_ref_spectrum14p;
     hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, x14::LDS_BYTES);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(kern, dim3(nblocks), dim3(x14::THREADS), x14::LDS_BYTES, s, rows, block_stride, twA, twB, (float4 *)refspec, xor80);
+    hipLaunchKernelGGL(kern, dim3(nblocks), dim3(x14::THREADS), x14::LDS_BYTES, s, rows, block_stride, reinterpret_cast<const c2 *>(twA),
+                       reinterpret_cast<const c2 *>(twB), (float4 *)refspec, xor80);
     return hipGetLastError();
 }
 
 static hipError_t launch_xcorr_lag14(hipStream_t s, const XcorrArgs &a, int row_count, const float2 *twA, const float2 *twB)
 {
-    // CRSDR_K1_VARIANT: "packed" (default) = xcorr14p.hpp, packed complex arithmetic; "scalar" = xcorr14.hpp, the same
-    // network on scalar fp32 ops (bit-identical results); "half" = xcorr14h.hpp, two rows per CU (experiment)
-    static const char variant = [] { const char *v = getenv("CRSDR_K1_VARIANT"); return v ? v[0] : 'p'; }();
+    const char variant = k1_variant();
     const bool half = variant == 'h';
-    if (variant == 'p' || variant == 'k') {
+    if (variant == 'p') {
         auto kp = x14p::k_xcorr_lag14p;
         hipError_t ep = hipFuncSetAttribute((const void *)kp, hipFuncAttributeMaxDynamicSharedMemorySize, x14::LDS_BYTES);
         if (ep != hipSuccess) return ep;
@@ -257,10 +271,18 @@ static hipError_t launch_long_fwd_cols(hipStream_t s, int nrows_launch, const in
 template <bool IS_REF>
 static hipError_t launch_long_rows(hipStream_t s, int n1, int nrows_launch, float2 *Y, const float2 *twA, const float2 *twB, float2 *refspec)
 {
-    auto kern = x14::k_rows14_cf32<IS_REF>;
+    if (k1_variant() == 's') {
+        auto kern = x14::k_rows14_cf32<IS_REF>;
+        hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, x14::LDS_BYTES);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(kern, dim3(n1, nrows_launch), dim3(x14::THREADS), x14::LDS_BYTES, s, Y, twA, twB, (float4 *)refspec);
+        return hipGetLastError();
+    }
+    auto kern = x14p::k_rows14_cf32p<IS_REF>;
     hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, x14::LDS_BYTES);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(kern, dim3(n1, nrows_launch), dim3(x14::THREADS), x14::LDS_BYTES, s, Y, twA, twB, (float4 *)refspec);
+    hipLaunchKernelGGL(kern, dim3(n1, nrows_launch), dim3(x14::THREADS), x14::LDS_BYTES, s, reinterpret_cast<c2 *>(Y), reinterpret_cast<const c2 *>(twA),
+                       reinterpret_cast<const c2 *>(twB), (float4 *)refspec);
     return hipGetLastError();
 }
 template <int LOG2N1>

@@ -281,6 +281,123 @@ __device__ __forceinline__ void xcorr_row14(const XcorrArgs &a, unsigned char *s
 }
 
 
+// ---- K0: reference spectrum, conj, [slot][group] layout ------------------------------------------
+__global__ __launch_bounds__(THREADS, 2) void k_ref_spectrum14p(const int8_t *__restrict__ rows, size_t block_stride,
+                                                               const c2 *__restrict__ twA,
+                                                               const c2 *__restrict__ twB,
+                                                               float4 *__restrict__ refspec_base, uint32_t xor80)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    c2 *A = reinterpret_cast<c2 *>(smem);
+    const float4 *A4 = reinterpret_cast<const float4 *>(smem);
+    const int tid = threadIdx.x;
+    const int8_t *ref_row = rows + (size_t)blockIdx.x * block_stride; // row 0 of batch block blockIdx.x
+    float4 *refspec4 = refspec_base + (size_t)blockIdx.x * (N / 2);
+    pass0_forward<true>(A, ref_row, twA, xor80, tid);
+    c2 wB[32];
+    tw_load(wB, twB, TWB_STRIDE, tid & 15);
+    __syncthreads();
+    pass1_forward(A, wB, tid);
+    wave_lds_sync();
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        // the 128 J groups of the 4 sub-blocks this wave produced in P1
+        const int g = ((tid >> 6) << 7) + 64 * h + (tid & 63), base = j_base(g), key = g & 7;
+        c2 u[16];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float4 q = A4[base + (j ^ key)];
+            u[2 * j] = mk(q.x, q.y);
+            u[2 * j + 1] = mk(q.z, q.w);
+        }
+        dft16p<-1>(u);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) // conj(sfft[0]) for the conjugate multiply of src/ccoherent.cc:177-179
+            refspec4[j * 1024 + g] = make_float4(u[2 * j].x, -u[2 * j].y, u[2 * j + 1].x, -u[2 * j + 1].y);
+    }
+}
+
+// ---- 16384-point row transforms on cf32 lines (stage B of the long-block path, longblock.hpp) ---------
+// Same three passes as K0 / K1 with a full (un-pruned) first radix-32 stage, cf32 in and out:
+//   IS_REF: forward, conj -> refspec [slot][group];   else: forward, x conj(ref), inverse, in place.
+// grid (N1 lines, rows); line l of row r at Y + (r * gridDim.x + l) * 16384.
+template <bool IS_REF>
+__global__ __launch_bounds__(THREADS, 2) void k_rows14_cf32p(c2 *__restrict__ Y, const c2 *__restrict__ twA,
+                                                             const c2 *__restrict__ twB, float4 *__restrict__ refspec_base)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    c2 *A = reinterpret_cast<c2 *>(smem);
+    float4 *A4 = reinterpret_cast<float4 *>(smem);
+    const int tid = threadIdx.x;
+    c2 *line = Y + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * N;
+    float4 *refspec4 = refspec_base + (size_t)blockIdx.x * (N / 2);
+    {
+        c2 v[32];
+#pragma unroll
+        for (int i = 0; i < 32; ++i) v[i] = line[i * 512 + tid];
+        dft32<-1>(v);
+        c2 w[32];
+        tw_load(w, twA, TWA_STRIDE, tid);
+        tw_apply<-1, true, 1>(v, w);
+        const int base = p0_base(tid);
+#pragma unroll
+        for (int k = 0; k < 32; ++k) A[base + k * 528] = v[xpos(k)];
+    }
+    c2 wB[32];
+    tw_load(wB, twB, TWB_STRIDE, tid & 15);
+    __syncthreads();
+    pass1_forward(A, wB, tid);
+    wave_lds_sync();
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int g = ((tid >> 6) << 7) + 64 * h + (tid & 63), base = j_base(g), key = g & 7;
+        float4 r[8];
+        if constexpr (!IS_REF) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) r[j] = refspec4[j * 1024 + g];
+        }
+        c2 u[16];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float4 q = A4[base + (j ^ key)];
+            u[2 * j] = mk(q.x, q.y);
+            u[2 * j + 1] = mk(q.z, q.w);
+        }
+        dft16p<-1>(u);
+        if constexpr (IS_REF) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                refspec4[j * 1024 + g] = make_float4(u[2 * j].x, -u[2 * j].y, u[2 * j + 1].x, -u[2 * j + 1].y);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                u[2 * j] = cmul(u[2 * j], mk(r[j].x, r[j].y));
+                u[2 * j + 1] = cmul(u[2 * j + 1], mk(r[j].z, r[j].w));
+            }
+            dft16p<+1>(u);
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                A4[base + (j ^ key)] = make_float4(u[2 * j].x, u[2 * j].y, u[2 * j + 1].x, u[2 * j + 1].y);
+        }
+    }
+    if constexpr (!IS_REF) {
+        wave_lds_sync();
+        pass1_inverse(A, wB, tid);
+        __syncthreads();
+        c2 v[32];
+        const int base = p0_base(tid);
+#pragma unroll
+        for (int k = 0; k < 32; ++k) v[k] = A[base + k * 528];
+        c2 w[32];
+        tw_load(w, twA, TWA_STRIDE, tid);
+        tw_apply<+1, false, 1>(v, w);
+        dft32<+1>(v);
+#pragma unroll
+        for (int i = 0; i < 32; ++i) line[i * 512 + tid] = v[xpos(i)]; // natural order, coalesced
+    }
+}
+
+
 __global__ __launch_bounds__(THREADS, 2) void k_xcorr_lag14p(XcorrArgs a, const float2 *__restrict__ twA,
                                                              const float2 *__restrict__ twB)
 {
