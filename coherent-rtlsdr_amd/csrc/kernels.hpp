@@ -19,6 +19,7 @@
 //   k_op_*              single-op kernels behind the per-op C ABI (class cdsp)
 #pragma once
 #include "arith.hpp"
+#include "cpk.hpp"
 #include "fft_lds.hpp"
 #include "plan_args.hpp"
 #include "xcorr14.hpp"
@@ -297,10 +298,27 @@ __global__ __launch_bounds__(kAlignThreads) void k_phase_dot(AlignArgs a)
 // then cdsp::convto8bit (src/cdsp.cc:51-54), single-rounding ops in the oracle's order
 __device__ __forceinline__ uint32_t rotq_word(uint32_t s, float2 p)
 {
-    const float2 y0 = rot_rn(make_float2(i8_to_f32(sext8(s, 0)), i8_to_f32(sext8(s, 1))), p);
-    const float2 y1 = rot_rn(make_float2(i8_to_f32(sext8(s, 2)), i8_to_f32(sext8(s, 3))), p);
-    return (uint32_t)(f32_to_i8_finite(y0.x) & 0xFF) | ((uint32_t)(f32_to_i8_finite(y0.y) & 0xFF) << 8) |
-           ((uint32_t)(f32_to_i8_finite(y1.x) & 0xFF) << 16) | ((uint32_t)(f32_to_i8_finite(y1.y) & 0xFF) << 24);
+    // On packed pairs (cpk.hpp): per sample  x = (I, Q) * (1/127)  [v_pk_mul],  t1 = x * p.x, t2 = (Q, I) * p.y  [2 v_pk_mul],
+    // y = (t1.x - t2.x, t1.y + t2.y)  [v_pk_add, neg_lo] -- the four products and two sums of rot_rn, each rounded once --
+    // then y * 127 [v_pk_mul], clamp, round-half-even, and  +128 -> v_cvt_pk_u8_f32 (exact on integers in [0, 255])
+    // straight into the byte lane; one XOR turns the four offset-binary bytes back into two's complement.
+    const c2 pp = c2{p.x, p.y};
+    uint32_t out = 0u;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        c2 x = c2{(float)sext8(s, 2 * h), (float)sext8(s, 2 * h + 1)};
+        x = x * (1.0f / 127.0f);
+        c2 t1, t2, y;
+        asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(t1) : "v"(x), "v"(pp));                                  // (I px, Q px)
+        asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[0,1]" : "=v"(t2) : "v"(x), "v"(pp));                     // (Q py, I py)
+        asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1]" : "=v"(y) : "v"(t1), "v"(t2));                                    // (I px - Q py, Q px + I py)
+        y = y * 127.0f;
+        const float r0 = rintf(__builtin_amdgcn_fmed3f(y.x, -128.0f, 127.0f)), r1 = rintf(__builtin_amdgcn_fmed3f(y.y, -128.0f, 127.0f));
+        const c2 u = c2{r0, r1} + 128.0f;
+        asm("v_cvt_pk_u8_f32 %0, %1, %2, %0" : "+v"(out) : "v"(u.x), "n"(2 * h));
+        asm("v_cvt_pk_u8_f32 %0, %1, %2, %0" : "+v"(out) : "v"(u.y), "n"(2 * h + 1));
+    }
+    return out ^ 0x80808080u;
 }
 
 // K2 chain: one thread per owned row walks the batch in block order.
