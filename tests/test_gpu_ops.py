@@ -153,3 +153,16 @@ def test_covariance_of_the_aligned_matrix_is_rank_one_dominated(b, synth):
     ph = np.angle(v[:, -1] * np.conj(v[0, -1]))
     assert np.abs(ph).max() < 0.05
     plan.close()
+
+
+def test_packed_complex_primitives_round_like_the_scalar_ones():
+    # csrc/cpk.hpp: complex product / conjugate product / +-i additions as v_pk_* instructions with operand modifiers
+    # must give the same bits as the scalar fma / mul / add formulations of fft_lds.hpp (tools/pk_check.hip, built
+    # by __graft_entry__.build()); the K1 kernels rely on it for "packed == scalar" (tests/test_gpu_plan.py)
+    import os, subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "tools", "pk_check")
+    if not os.path.exists(exe):
+        subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "--offload-arch=gfx950", "-ffp-contract=off", "-o", exe, exe + ".hip"], check=True)
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "mismatches 0" in r.stdout, r.stdout + r.stderr
