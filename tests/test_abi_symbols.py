@@ -61,3 +61,21 @@ def test_product_never_imports_the_oracle():
             if f.endswith((".py", ".hip", ".hpp", ".h", ".cc", ".cpp", ".c")) or f == "Makefile":
                 text = open(os.path.join(dirpath, f), errors="replace").read()
                 assert "oracle_py" not in text and "coherent_oracle" not in text and "liboracle" not in text, f
+
+
+def test_header_is_plain_c99_and_links_from_c(b, tmp_path):
+    # the boundary is a C ABI (cgo / JNI / ctypes bind it): include/crsdr.h must compile as strict C99 and the
+    # library must link from a C program.  On this CPU-only box the calls then fail loudly with CRSDR_ENODEV.
+    import subprocess
+    so_dir = os.path.dirname(b._SO)
+    exe = tmp_path / "abi_c99"
+    r = subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", os.path.join(ROOT, "include"),
+                        "-o", str(exe), os.path.join(ROOT, "tests", "c", "abi_c99.c"), "-L", so_dir, "-lcrsdr", f"-Wl,-rpath,{so_dir}"],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and "abi 1" in out.stdout, out.stdout + out.stderr
+    if b.device_count() < 1:
+        assert "rc -4" in out.stdout and "plan_create rc -4" in out.stdout
+    else:
+        assert "plan_create rc 0" in out.stdout
