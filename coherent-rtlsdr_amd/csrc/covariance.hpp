@@ -7,7 +7,7 @@
 //    (a . b,  swap16(a) . even_bytes(b),  swap16(a) . odd_bytes(b)), exact in int32 (|sum| <= 2^15 L),
 // -> mean removal and the 1/(127^2 L) scale in fp64 in the epilogue.
 // Both MFMA operands are rows of the same row-major matrix, so no transposes and no LDS: each lane
-// loads the 16 contiguous bytes of "its" row and K-slice.
+// loads the 16 contiguous bytes of "its" row and K-slice.  Hermitian: only tiles on / above the diagonal are formed.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -46,6 +46,8 @@ __global__ __launch_bounds__(256) void k_covariance(const int8_t *__restrict__ m
     const int nsig = nrows - 1, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int a0 = blockIdx.y * 64 + (wave >> 1) * 32, b0 = blockIdx.x * 64 + (wave & 1) * 32;
     if (a0 >= nsig || b0 >= nsig) return; // wave-uniform
+    // Rxx is Hermitian: only the 32 x 32 tiles on or above the diagonal are formed, the rest is their conjugate transpose
+    if (b0 < a0) return;
     const int ra = min(a0 + (lane & 31), nsig - 1), rb = min(b0 + (lane & 31), nsig - 1); // clamp: padded rows are masked at the store
     const v4i *pa = reinterpret_cast<const v4i *>(matrix + (size_t)(1 + ra) * B) + (lane >> 5);
     const v4i *pb = reinterpret_cast<const v4i *>(matrix + (size_t)(1 + rb) * B) + (lane >> 5);
@@ -74,6 +76,7 @@ __global__ __launch_bounds__(256) void k_covariance(const int8_t *__restrict__ m
                 const double re = ((double)g1[r] / L - ((double)sa.x * sb.x + (double)sa.y * sb.y) / (L * L)) * scale;
                 const double im = ((double)(g3[r] - g2[r]) / L - ((double)sa.x * sb.y - (double)sa.y * sb.x) / (L * L)) * scale;
                 rxx[(size_t)row * nsig + col] = make_float2((float)re, (float)im);
+                if (b0 > a0) rxx[(size_t)col * nsig + row] = make_float2((float)re, -(float)im);   // mirrored tile
             }
         }
     }
