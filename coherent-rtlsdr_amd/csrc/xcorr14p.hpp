@@ -176,7 +176,7 @@ __device__ __forceinline__ void xcorr_row14(const XcorrArgs &a, unsigned char *s
     wave_lds_sync();
     CRSDR_STAMP(3);
     // junction: DFT16 . conj(ref spectrum) . IDFT16 on the same 16 contiguous points
-#pragma unroll
+#pragma unroll 1     // not unrolled: both halves in flight need 238 VGPRs, one at a time 193 (room for a phase-kernel wave per SIMD)
     for (int h = 0; h < 2; ++h) {
         // the 128 J groups of the 4 sub-blocks this wave produced in P1 (and consumes in P1')
         const int g = ((tid >> 6) << 7) + 64 * h + (tid & 63), base = j_base(g), key = g & 7;
