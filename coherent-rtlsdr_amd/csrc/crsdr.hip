@@ -568,6 +568,13 @@ struct crsdr_plan {
     size_t packet_bytes = 0, matrix_off = 0, packet_stride = 0, own_packet_stride = 0;
     hipStream_t own_stream = nullptr, stream = nullptr, aux = nullptr;
     hipEvent_t ev_fork = nullptr, ev_ref[2] = {nullptr, nullptr}, ev_k1done[2] = {nullptr, nullptr};
+    // K1 on its own stream beside the phase kernel of the previous batch (see crsdr_plan_submit_batch): per-batch
+    // {lag, mag, frac} are double-buffered (obuf), ev_k2done[i] = the phase kernel that read buffer i has finished
+    hipStream_t xs = nullptr;
+    hipEvent_t ev_k2done[2] = {nullptr, nullptr};
+    bool k2done_valid[2] = {false, false};
+    int obuf = 0;
+    bool overlap = false, last_locked = false;   // overlap: CRSDR_OVERLAP=1 (measured neutral)
     hipEvent_t ev_start = nullptr, ev_stop = nullptr;
     bool k1done_valid[2] = {false, false};
     int slot = 0;
@@ -626,9 +633,9 @@ static int plan_init_state(crsdr_plan *p)
     ph[0] = make_float2(0.0f, 0.0f);                     // pcorrection[0] is never written
     for (int i = 0; i < 2; ++i) HIP_TRY(hipMemcpy(p->d_phase_state[i], ph.data(), sizeof(float2) * n, hipMemcpyHostToDevice));
     for (size_t t = 0; t < T; ++t) HIP_TRY(hipMemcpy(p->d_phasor + t * n, ph.data(), sizeof(float2) * n, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemset(p->d_lag, 0, sizeof(int32_t) * n * T));
-    HIP_TRY(hipMemset(p->d_mag, 0, sizeof(float) * n * T));
-    HIP_TRY(hipMemset(p->d_frac, 0, sizeof(float) * n * T));
+    HIP_TRY(hipMemset(p->d_lag, 0, sizeof(int32_t) * n * T * 2));
+    HIP_TRY(hipMemset(p->d_mag, 0, sizeof(float) * n * T * 2));
+    HIP_TRY(hipMemset(p->d_frac, 0, sizeof(float) * n * T * 2));
     HIP_TRY(hipMemset(p->d_lag_state, 0, sizeof(int32_t) * n));
     HIP_TRY(hipMemset(p->d_mag_state, 0, sizeof(float) * n));
     HIP_TRY(hipMemset(p->d_frac_state, 0, sizeof(float) * n));
@@ -643,8 +650,10 @@ static int plan_alloc(crsdr_plan *p)
     HIP_TRY(hipSetDevice(p->device));
     HIP_TRY(hipStreamCreateWithFlags(&p->own_stream, hipStreamNonBlocking));
     HIP_TRY(hipStreamCreateWithFlags(&p->aux, hipStreamNonBlocking));
+    HIP_TRY(hipStreamCreateWithFlags(&p->xs, hipStreamNonBlocking));
+    { const char *e = getenv("CRSDR_OVERLAP"); if (e) p->overlap = atoi(e) != 0; }
     p->stream = p->own_stream;
-    hipEvent_t *evs[] = {&p->ev_fork, &p->ev_ref[0], &p->ev_ref[1], &p->ev_k1done[0], &p->ev_k1done[1]};
+    hipEvent_t *evs[] = {&p->ev_fork, &p->ev_ref[0], &p->ev_ref[1], &p->ev_k1done[0], &p->ev_k1done[1], &p->ev_k2done[0], &p->ev_k2done[1]};
     for (auto e : evs) HIP_TRY(hipEventCreateWithFlags(e, hipEventDisableTiming));
     for (int i = 0; i < kStageSlots; ++i) HIP_TRY(hipEventCreateWithFlags(&p->ev_stage[i], hipEventDisableTiming));
     HIP_TRY(hipEventCreate(&p->ev_start));
@@ -681,9 +690,9 @@ static int plan_alloc(crsdr_plan *p)
     p->d_packet = p->d_packet_own;
     HIP_TRY(hipMalloc((void **)&p->d_readcnt, sizeof(uint32_t) * n * T));
     HIP_TRY(hipMalloc((void **)&p->d_mask, n));
-    HIP_TRY(hipMalloc((void **)&p->d_lag, sizeof(int32_t) * n * T));
-    HIP_TRY(hipMalloc((void **)&p->d_mag, sizeof(float) * n * T));
-    HIP_TRY(hipMalloc((void **)&p->d_frac, sizeof(float) * n * T));
+    HIP_TRY(hipMalloc((void **)&p->d_lag, sizeof(int32_t) * n * T * 2));   // two batches: K1 of batch b+1 runs beside the phase kernel of batch b
+    HIP_TRY(hipMalloc((void **)&p->d_mag, sizeof(float) * n * T * 2));
+    HIP_TRY(hipMalloc((void **)&p->d_frac, sizeof(float) * n * T * 2));
     HIP_TRY(hipMalloc((void **)&p->d_phasor, sizeof(float2) * n * T));
     HIP_TRY(hipMalloc((void **)&p->d_corr, sizeof(long long) * 2 * n * T));
     HIP_TRY(hipMalloc((void **)&p->d_sync, 64));
@@ -704,18 +713,20 @@ static void plan_free(crsdr_plan *p)
     (void)hipSetDevice(p->device);
     if (p->own_stream) (void)hipStreamSynchronize(p->own_stream);
     if (p->aux) (void)hipStreamSynchronize(p->aux);
+    if (p->xs) (void)hipStreamSynchronize(p->xs);
     void *bufs[] = {p->d_wc, p->d_wf, p->d_tw1, p->d_Y, p->d_Yref, p->d_part, p->d_tw, p->d_twA, p->d_twB, p->d_refspec[0], p->d_refspec[1], p->d_rows, p->d_packet_alloc, p->d_readcnt,
                     p->d_mask, p->d_lag, p->d_mag, p->d_frac, p->d_phasor, p->d_corr, p->d_sync, p->d_lag_state, p->d_mag_state,
                     p->d_frac_state, p->d_phase_state[0], p->d_phase_state[1]};
     for (void *b : bufs) if (b) (void)hipFree(b);
     if (p->h_readcnt) (void)hipHostFree(p->h_readcnt);
     if (p->h_mask) (void)hipHostFree(p->h_mask);
-    hipEvent_t evs[] = {p->ev_fork, p->ev_ref[0], p->ev_ref[1], p->ev_k1done[0], p->ev_k1done[1], p->ev_start, p->ev_stop};
+    hipEvent_t evs[] = {p->ev_fork, p->ev_ref[0], p->ev_ref[1], p->ev_k1done[0], p->ev_k1done[1], p->ev_k2done[0], p->ev_k2done[1], p->ev_start, p->ev_stop};
     for (hipEvent_t e : evs) if (e) (void)hipEventDestroy(e);
     for (int i = 0; i < kStageSlots; ++i) if (p->ev_stage[i]) (void)hipEventDestroy(p->ev_stage[i]);
     for (hipEvent_t e : p->prof_ev) if (e) (void)hipEventDestroy(e);
     if (p->own_stream) (void)hipStreamDestroy(p->own_stream);
     if (p->aux) (void)hipStreamDestroy(p->aux);
+    if (p->xs) (void)hipStreamDestroy(p->xs);
     delete p;
 }
 
@@ -768,6 +779,7 @@ extern "C" int crsdr_plan_sync(crsdr_plan *p)
     HIP_TRY(hipSetDevice(p->device));
     HIP_TRY(hipStreamSynchronize(p->stream));
     HIP_TRY(hipStreamSynchronize(p->aux));
+    HIP_TRY(hipStreamSynchronize(p->xs));
     return check_fused_status(p);
 }
 
@@ -829,9 +841,10 @@ extern "C" int crsdr_plan_device_buffers(crsdr_plan *p, void **packet, void **la
 {
     if (!p) return fail(CRSDR_EINVAL, "plan_device_buffers: NULL plan");
     if (packet) *packet = p->d_packet;
-    if (lag) *lag = p->d_lag;
-    if (mag) *mag = p->d_mag;
-    if (frac) *frac = p->d_frac;
+    const size_t ob = (size_t)p->obuf * (size_t)p->nrows * (size_t)p->max_batch;   // the buffers of the last submit
+    if (lag) *lag = p->d_lag + ob;
+    if (mag) *mag = p->d_mag + ob;
+    if (frac) *frac = p->d_frac + ob;
     if (phasor) *phasor = p->d_phasor;
     return CRSDR_OK;
 }
@@ -912,16 +925,40 @@ extern "C" int crsdr_plan_submit_batch(crsdr_plan *p, const void *rows, int mem_
     }
 
     const int pin = p->phase_cur, pout = pin ^ 1;
+    const int obuf = (p->obuf ^= 1);                      // this batch's {lag, mag, frac}
+    const size_t ooff = (size_t)obuf * n * (size_t)p->max_batch;
+    int32_t *o_lag = p->d_lag + ooff;
+    float *o_mag = p->d_mag + ooff, *o_frac = p->d_frac + ooff;
     AlignArgs aa;
     aa.rows = d_in; aa.block_stride = d_stride; aa.packet = p->d_packet; aa.packet_stride = p->packet_stride;
-    aa.readcnt = d_readcnt; aa.lag_mask = d_mask; aa.lag = p->d_lag; aa.lag_state = p->d_lag_state; aa.corr = p->d_corr;
+    aa.readcnt = d_readcnt; aa.lag_mask = d_mask; aa.lag = o_lag; aa.lag_state = p->d_lag_state; aa.corr = p->d_corr;
     aa.phase_in = p->d_phase_state[pin]; aa.phase_out = p->d_phase_state[pout]; aa.phasor = p->d_phasor;
     aa.nrows = p->nrows; aa.B = p->B; aa.row_begin = p->row_begin; aa.nblocks = nblocks;
     aa.digital = (p->mode == CRSDR_MODE_DIGITAL); aa.refnoise = (flags & CRSDR_REFNOISE_ENABLED) ? 1 : 0;
     aa.xcorr_ran = any_lag ? 1 : 0;
     aa.seq = seq; aa.xor80 = xor80;
     aa.slab = p->d_slab; aa.slab_stride = p->slab_stride; aa.hdr_first = p->hdr_first; aa.hdr_count = p->hdr_count;
-    aa.lag_out = p->d_lag; aa.mag_out = p->d_mag; aa.frac_out = p->d_frac; aa.mag_state = p->d_mag_state; aa.frac_state = p->d_frac_state;
+    aa.lag_out = o_lag; aa.mag_out = o_mag; aa.frac_out = o_frac; aa.mag_state = p->d_mag_state; aa.frac_state = p->d_frac_state;
+
+    // 16-byte accesses need 16-byte aligned rows and matrix rows (always true for the plan's own
+    // buffers; a caller-bound packet or device input may only be 4-byte aligned -> word kernels)
+    const bool vec16 = ((uintptr_t)d_in % 16 == 0) && (d_stride % 16 == 0) && (((uintptr_t)p->d_packet + p->matrix_off) % 16 == 0) &&
+                       (p->packet_stride % 16 == 0 || nblocks == 1) &&
+                       (!p->d_slab || ((uintptr_t)p->d_slab % 16 == 0 && p->slab_stride % 16 == 0));
+    const int chunks = p->B > 16384 ? p->B / 16384 : 1; // long rows: 16 KiB of the row per workgroup
+    const bool fused = p->fused_k2 && vec16 && chunks == 1;
+    // Optional stream layout of a batch (CRSDR_OVERLAP=1; B <= 16384, fused phase kernel):
+    //   aux: K0(b)        X: K1(b)        S: phase kernel(b)
+    // K1 leaves 112 VGPRs per SIMD and 28 KiB of LDS unused and the phase kernel is HBM bound and small in registers, so
+    // with K1 of batch b+1 on its own stream the two do share the CUs.  What makes that legal: per-batch {lag, mag,
+    // frac} are double-buffered (K1(b+1) writes the other buffer; K1(b+2) waits for the phase kernel of batch b), the
+    // carried lag / mag / frac state is only touched on X (the phase kernel reads the per-batch arrays, into which K1
+    // republishes the state of rows that were not requested), and a batch without cross-correlation, which does read
+    // the state on S, is waited for by the next K1.  Measured: throughput unchanged (16.1 k blocks/s either way) -- K1
+    // stretches by exactly what the phase kernel costs alone (0.83 -> 0.96 ms per launch): extra waves take issue
+    // slots from K1's two waves per SIMD rather than filling their stalls.  Off by default.
+    const bool use_x = p->overlap && fused && any_lag && !p->longblock;
+    hipStream_t KS = use_x ? p->xs : S;
 
     if (any_lag && p->longblock) {
         // B = N1 x 16384: column FFTs -> row FFTs (x conj ref, inverse) -> inverse column FFTs + argmax -> finalize
@@ -935,7 +972,7 @@ extern "C" int crsdr_plan_submit_batch(crsdr_plan *p, const void *rows, int mem_
         XcorrArgs xa;
         xa.rows = d_in; xa.block_stride = d_stride; xa.refspec = p->d_refspec[0]; xa.lag_mask = d_mask;
         xa.row_begin = p->row_begin; xa.nrows = p->nrows; xa.nblocks = 1; xa.xor80 = xor80; xa.stagger = 0;
-        xa.lag = p->d_lag; xa.mag = p->d_mag; xa.frac = p->d_frac;
+        xa.lag = o_lag; xa.mag = o_mag; xa.frac = o_frac;
         xa.lag_state = p->d_lag_state; xa.mag_state = p->d_mag_state; xa.frac_state = p->d_frac_state;
         hipEvent_t *pe1 = prof_pair(p, CRSDR_KERNEL_XCORR_LAG);
         if (pe1) HIP_TRY(hipEventRecord(pe1[0], S));
@@ -953,9 +990,10 @@ extern "C" int crsdr_plan_submit_batch(crsdr_plan *p, const void *rows, int mem_
     } else if (any_lag) {
         const int slot = (p->slot ^= 1);
         // K0 on the aux stream: with resident input it overlaps the previous batch's K1 / K2
-        if (!input_ready) {
-            HIP_TRY(hipEventRecord(p->ev_fork, S)); // input copies / the caller's producer work
-            HIP_TRY(hipStreamWaitEvent(A, p->ev_fork, 0));
+        const bool forked = !input_ready || d_readcnt || d_mask;
+        if (forked) {
+            HIP_TRY(hipEventRecord(p->ev_fork, S)); // input copies, mask copy / the caller's producer work
+            if (!input_ready) HIP_TRY(hipStreamWaitEvent(A, p->ev_fork, 0));
         }
         if (p->k1done_valid[slot]) HIP_TRY(hipStreamWaitEvent(A, p->ev_k1done[slot], 0)); // refspec[slot] free again
         hipEvent_t *pe0 = prof_pair(p, CRSDR_KERNEL_REF_SPECTRUM);
@@ -969,26 +1007,25 @@ extern "C" int crsdr_plan_submit_batch(crsdr_plan *p, const void *rows, int mem_
         xa.rows = d_in; xa.block_stride = d_stride; xa.refspec = p->d_refspec[slot]; xa.lag_mask = d_mask;
         xa.row_begin = p->row_begin; xa.nrows = p->nrows; xa.nblocks = nblocks; xa.xor80 = xor80;
         { const char *sg = getenv("CRSDR_K1_STAGGER"); xa.stagger = sg ? atoi(sg) : 0; } // x 512 cycles; 0 is best for the packed kernel, 1 for the scalar one
-        xa.lag = p->d_lag; xa.mag = p->d_mag; xa.frac = p->d_frac;
+        xa.lag = o_lag; xa.mag = o_mag; xa.frac = o_frac;
         xa.lag_state = p->d_lag_state; xa.mag_state = p->d_mag_state; xa.frac_state = p->d_frac_state;
-        HIP_TRY(hipStreamWaitEvent(S, p->ev_ref[slot], 0));
+        HIP_TRY(hipStreamWaitEvent(KS, p->ev_ref[slot], 0));
+        if (use_x) {
+            if (forked) HIP_TRY(hipStreamWaitEvent(KS, p->ev_fork, 0));
+            if (p->k2done_valid[obuf]) HIP_TRY(hipStreamWaitEvent(KS, p->ev_k2done[obuf], 0));            // lag[obuf] free again
+            if (p->last_locked && p->k2done_valid[obuf ^ 1]) HIP_TRY(hipStreamWaitEvent(KS, p->ev_k2done[obuf ^ 1], 0)); // it read the state
+        }
         hipEvent_t *pe1 = prof_pair(p, CRSDR_KERNEL_XCORR_LAG);
-        if (pe1) HIP_TRY(hipEventRecord(pe1[0], S));
-        if (p->log2n == 14) HIP_TRY(launch_xcorr_lag14(S, xa, p->row_count, p->d_twA, p->d_twB));
-        else HIP_TRY(CRSDR_DISPATCH_LOG2(p->log2n, (launch_xcorr_lag<LG>(S, xa, p->row_count, p->d_tw))));
-        if (pe1) HIP_TRY(hipEventRecord(pe1[1], S));
-        HIP_TRY(hipEventRecord(p->ev_k1done[slot], S));
+        if (pe1) HIP_TRY(hipEventRecord(pe1[0], KS));
+        if (p->log2n == 14) HIP_TRY(launch_xcorr_lag14(KS, xa, p->row_count, p->d_twA, p->d_twB));
+        else HIP_TRY(CRSDR_DISPATCH_LOG2(p->log2n, (launch_xcorr_lag<LG>(KS, xa, p->row_count, p->d_tw))));
+        if (pe1) HIP_TRY(hipEventRecord(pe1[1], KS));
+        HIP_TRY(hipEventRecord(p->ev_k1done[slot], KS));
         p->k1done_valid[slot] = true;
+        if (use_x) HIP_TRY(hipStreamWaitEvent(S, p->ev_k1done[slot], 0));
     }
-    // 16-byte accesses need 16-byte aligned rows and matrix rows (always true for the plan's own
-    // buffers; a caller-bound packet or device input may only be 4-byte aligned -> word kernels)
-    const bool vec16 = ((uintptr_t)d_in % 16 == 0) && (d_stride % 16 == 0) && (((uintptr_t)p->d_packet + p->matrix_off) % 16 == 0) &&
-                       (p->packet_stride % 16 == 0 || nblocks == 1) &&
-                       (!p->d_slab || ((uintptr_t)p->d_slab % 16 == 0 && p->slab_stride % 16 == 0));
-    // phase path: faithful mode does not depend on this batch's lags, digital mode does; either
-    // way it follows K1 on the main stream (K1 is VALU bound, these two are the HBM-bound tail)
-    const int chunks = p->B > 16384 ? p->B / 16384 : 1; // long rows: 16 KiB of the row per workgroup
-    if (p->fused_k2 && vec16 && chunks == 1) {
+    // (a batch that runs entirely on S needs no extra wait: every earlier K1 on X was awaited by its own phase kernel on S)
+    if (fused) {
         // fused phase path: every row is read once (k_align_fused); timed under CRSDR_KERNEL_ALIGN_QUANT
         static const int spin_limit = [] { const char *e = getenv("CRSDR_K2_SPIN"); return e ? atoi(e) : kFusedSpinLimit; }();
         FusedSync fs{p->d_sync, p->d_sync + 1, reinterpret_cast<unsigned long long *>(p->d_corr), p->row_count, spin_limit};
@@ -998,6 +1035,9 @@ extern "C" int crsdr_plan_submit_batch(crsdr_plan *p, const void *rows, int mem_
         hipLaunchKernelGGL(k_align_fused, dim3((unsigned)((1 + p->row_count) * nblocks)), dim3(kAlignThreads), 0, S, aa, fs);
         HIP_TRY(hipGetLastError());
         if (pe) HIP_TRY(hipEventRecord(pe[1], S));
+        HIP_TRY(hipEventRecord(p->ev_k2done[obuf], S));
+        p->k2done_valid[obuf] = true;
+        p->last_locked = !any_lag;
         p->fused_used = true;
         p->phase_cur = pout;
         p->last_nblocks = nblocks;
@@ -1024,6 +1064,9 @@ extern "C" int crsdr_plan_submit_batch(crsdr_plan *p, const void *rows, int mem_
         HIP_TRY(hipGetLastError());
         if (pe) HIP_TRY(hipEventRecord(pe[1], S));
     }
+    HIP_TRY(hipEventRecord(p->ev_k2done[obuf], S));
+    p->k2done_valid[obuf] = true;
+    p->last_locked = !any_lag;
     p->phase_cur = pout;
     p->last_nblocks = nblocks;
     if (p->prof_slots) { if (p->prof_mask & (1u << 31)) HIP_TRY(hipEventRecord(p->ev_stop, S)); p->prof_count++; }
@@ -1061,9 +1104,10 @@ extern "C" int crsdr_plan_fetch_block(crsdr_plan *p, int block, int32_t *lag, fl
     HIP_TRY(hipStreamSynchronize(p->stream));
     { int rc_ = check_fused_status(p); if (rc_) return rc_; }
     const size_t n = (size_t)p->nrows, o = (size_t)block * n;
-    if (lag) HIP_TRY(hipMemcpy(lag, p->d_lag + o, sizeof(int32_t) * n, hipMemcpyDeviceToHost));
-    if (mag) HIP_TRY(hipMemcpy(mag, p->d_mag + o, sizeof(float) * n, hipMemcpyDeviceToHost));
-    if (frac) HIP_TRY(hipMemcpy(frac, p->d_frac + o, sizeof(float) * n, hipMemcpyDeviceToHost));
+    const size_t ob = (size_t)p->obuf * n * (size_t)p->max_batch + o;
+    if (lag) HIP_TRY(hipMemcpy(lag, p->d_lag + ob, sizeof(int32_t) * n, hipMemcpyDeviceToHost));
+    if (mag) HIP_TRY(hipMemcpy(mag, p->d_mag + ob, sizeof(float) * n, hipMemcpyDeviceToHost));
+    if (frac) HIP_TRY(hipMemcpy(frac, p->d_frac + ob, sizeof(float) * n, hipMemcpyDeviceToHost));
     if (phasor) HIP_TRY(hipMemcpy(phasor, p->d_phasor + o, sizeof(float2) * n, hipMemcpyDeviceToHost));
     if (packet) HIP_TRY(hipMemcpy(packet, p->d_packet + (size_t)block * p->packet_stride, p->packet_bytes, hipMemcpyDeviceToHost));
     return CRSDR_OK;

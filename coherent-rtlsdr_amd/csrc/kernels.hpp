@@ -185,8 +185,10 @@ constexpr int kAlignThreads = 256;
 __device__ __forceinline__ int align_shift(const AlignArgs &a, int row, int t)
 {
     if (!a.digital) return 0;
-    const bool requested = a.xcorr_ran && (!a.lag_mask || a.lag_mask[row]);
-    return requested ? a.lag[(size_t)t * a.nrows + row] : a.lag_state[row];
+    // when the cross-correlation ran, its kernels wrote lag[t][row] for every owned row -- measured, or the carried
+    // value republished for a row that was not requested (xcorr_skip) -- so the carried state itself, which the
+    // next batch's K1 may already be updating on its own stream, is only read by batches that ran no K1
+    return a.xcorr_ran ? a.lag[(size_t)t * a.nrows + row] : a.lag_state[row];
 }
 
 // one 32-bit word = samples (2i, 2i+1) of the row shifted by d: y[n] = s[n + d], zero outside [0,L)

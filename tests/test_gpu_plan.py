@@ -569,11 +569,12 @@ def test_phase_path_variants_are_bit_identical(tmp_path):
                  lag=np.stack([r["lag"] for r in res]), mag=np.stack([r["mag"] for r in res]))
     ''') % root
     outs = {}
-    for name, env in (("fused", {}), ("fallback", {"CRSDR_K2_SPIN": "0"}), ("three", {"CRSDR_K2_FUSED": "0"})):
+    for name, env in (("fused", {}), ("fallback", {"CRSDR_K2_SPIN": "0"}), ("three", {"CRSDR_K2_FUSED": "0"}),
+                      ("overlap", {"CRSDR_OVERLAP": "1"})):            # K1 of the next batch beside this batch's phase kernel
         out = tmp_path / f"{name}.npz"
         r = subprocess.run([sys.executable, "-c", code, str(out)], env=dict(os.environ, **env), capture_output=True, text=True, timeout=300)
         assert r.returncode == 0, r.stdout + r.stderr
         outs[name] = np.load(out)
-    for other in ("fallback", "three"):
+    for other in ("fallback", "three", "overlap"):
         for key in ("phasor", "packet", "lag", "mag"):
             assert np.array_equal(outs["fused"][key].view(np.uint8), outs[other][key].view(np.uint8)), (other, key)
