@@ -12,6 +12,7 @@ namespace x14p {
 using x14::N; using x14::L; using x14::THREADS; using x14::LDS_ELEMS; using x14::LDS_BYTES; using x14::TWA_STRIDE; using x14::TWB_STRIDE;
 using x14::kInvScale2; using x14::kCos16; using x14::xpos; using x14::p0_base; using x14::p1_off; using x14::p1_swz; using x14::j_base;
 using x14::wave_lds_sync;
+typedef __attribute__((address_space(3))) c2 lds_c2;    // an LDS-qualified access (a volatile one through a generic pointer would be a flat load)
 
 // a * W_32^K  (forward exp(-2 pi i K / 32); DIR > 0: conjugate), K in [0,16)
 template <int DIR, int K>
@@ -128,7 +129,8 @@ __device__ __forceinline__ void pass1_forward(c2 *A, const c2 *w, int tid)
     c2 *Ab = A + blk * 528;
     c2 v[32];
 #pragma unroll
-    for (int i = 0; i < 32; ++i) v[i] = Ab[p1_off(i) + (n2 ^ p1_swz(i))];
+    // volatile: keeps these as 32 ds_read_b64 (2 LDS cycles each); merged into ds_read2_b64 they cost 8 cycles per pair
+    for (int i = 0; i < 32; ++i) v[i] = *(const volatile lds_c2 *)(Ab + p1_off(i) + (n2 ^ p1_swz(i)));
     dft32<-1>(v);
     tw_apply<-1, true, 1>(v, w);
 #pragma unroll
@@ -141,7 +143,7 @@ __device__ __forceinline__ void pass1_inverse(c2 *A, const c2 *w, int tid)
     c2 *Ab = A + blk * 528;
     c2 v[32];
 #pragma unroll
-    for (int k = 0; k < 32; ++k) v[k] = Ab[p1_off(k) + (n2 ^ p1_swz(k))];
+    for (int k = 0; k < 32; ++k) v[k] = *(const volatile lds_c2 *)(Ab + p1_off(k) + (n2 ^ p1_swz(k)));   // ds_read_b64, not read2 (see pass1_forward)
     tw_apply<+1, false, 1>(v, w);
     dft32<+1>(v);
 #pragma unroll
