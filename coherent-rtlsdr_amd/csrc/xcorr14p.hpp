@@ -100,7 +100,7 @@ __device__ __forceinline__ void tw_apply(c2 *v, const c2 *w)
 
 template <bool IS_REF>
 __device__ __forceinline__ void pass0_forward(c2 *A, const int8_t *__restrict__ row, const c2 *__restrict__ twA,
-                                              uint32_t xor80, int tid)
+                                              uint32_t xor80, int tid, c2 *w)
 {
     c2 v[32];
     const uint16_t *src = reinterpret_cast<const uint16_t *>(row);
@@ -115,8 +115,7 @@ __device__ __forceinline__ void pass0_forward(c2 *A, const int8_t *__restrict__ 
     dft32_stage1_pruned<0, IS_REF>(v);
     dft16p<-1>(v);
     dft16p<-1>(v + 16);
-    c2 w[32];
-    tw_load(w, twA, TWA_STRIDE, tid);
+    tw_load(w, twA, TWA_STRIDE, tid);           // w: the caller's array -- K1 keeps the column twiddles for its last pass
     tw_apply<-1, true, 1>(v, w);
     const int base = p0_base(tid);
 #pragma unroll
@@ -161,7 +160,8 @@ __device__ __forceinline__ void xcorr_row14(const XcorrArgs &a, unsigned char *s
     const float4 *__restrict__ refspec4 = reinterpret_cast<const float4 *>(a.refspec) + (size_t)t * (N / 2);
 
     CRSDR_STAMP(0);
-    pass0_forward<false>(A, src, twA, a.xor80, tid);
+    c2 wA[32];                                   // column twiddles: P0 applies them, P0' their conjugates -- one chain, 62 registers
+    pass0_forward<false>(A, src, twA, a.xor80, tid, wA);
     CRSDR_STAMP(1);
     // P1 / P1' twiddles: one chain per row, computed while the P0 stores drain, alive across J
     c2 wB[32];
@@ -216,9 +216,7 @@ __device__ __forceinline__ void xcorr_row14(const XcorrArgs &a, unsigned char *s
         const int base = p0_base(tid);
 #pragma unroll
         for (int k = 0; k < 32; ++k) v[k] = A[base + k * 528];
-        c2 w[32];
-        tw_load(w, twA, TWA_STRIDE, tid);
-        tw_apply<+1, false, 1>(v, w);
+        tw_apply<+1, false, 1>(v, wA);
         dft32<+1>(v);
 #pragma unroll
         for (int i = 0; i < 32; ++i) {
@@ -295,7 +293,8 @@ __global__ __launch_bounds__(THREADS, 2) void k_ref_spectrum14p(const int8_t *__
     const int tid = threadIdx.x;
     const int8_t *ref_row = rows + (size_t)blockIdx.x * block_stride; // row 0 of batch block blockIdx.x
     float4 *refspec4 = refspec_base + (size_t)blockIdx.x * (N / 2);
-    pass0_forward<true>(A, ref_row, twA, xor80, tid);
+    c2 wA0[32];
+    pass0_forward<true>(A, ref_row, twA, xor80, tid, wA0);
     c2 wB[32];
     tw_load(wB, twB, TWB_STRIDE, tid & 15);
     __syncthreads();
