@@ -22,4 +22,9 @@ r1 = np.zeros(2048,dtype=np.int8)
 for r in range(6):
     lib.csynth_make_row(pp,2,r,-1.0,r1.ctypes.data); assert np.array_equal(r1, rows[r])
 lib.csynth_params_destroy(pp)
+# beamformer restatement: covariance -> noise subspace -> MUSIC scan
+rng = np.random.default_rng(5)
+mat = rng.integers(-100, 100, size=(22, 2048), dtype=np.int8)
+rxx = O.covariance(mat); vec, sv = O.noisesubspace(rxx); pm = O.pmusic2d(vec, 1, 0.5063, 7, 3, 20, 20)
+assert np.all(np.isfinite(pm)) and np.all(np.diff(sv) <= 1e-6)
 print("sanitizer run ok")
