@@ -401,7 +401,18 @@ def _cpu_baseline(args, rows, nrows, B, mode):
     for i in range(nbm):
         eng.block(rows, seq=i, nthreads=nthreads)
     dtm = time.perf_counter() - t0
+    # the reference as shipped: at most nfft = 8 rows (ref + 7) are cross-correlated per block (src/main.cc:165,
+    # src/ccoherent.cc:124); every row still goes through the phase path
+    eng8 = O.Engine(nrows, B, mode, nfft_cap=8)
+    eng8.block(rows)
+    nb8 = max(2, min(16, int(4.0 / max(one / 8, 1e-3))))
+    t0 = time.perf_counter()
+    for i in range(nb8):
+        eng8.block(rows, seq=i)
+    dt8 = time.perf_counter() - t0
     return {"value": nb / dt1, "unit": "blocks/s", "cores": 1, "kind": "port",
+            "ref8": {"value": nb8 / dt8, "cores": 1, "sample": f"{nb8} blocks with the reference's nfft = 8 queue cap (7 of the {nrows - 1} "
+                                                               f"signal rows get a lag per block, all get the phase path)"},
             "sample": f"{nb} blocks of the same {nrows} x {B // 2} workload, oracle/coherent_oracle.c -O3 -mavx2, 1 thread "
                       f"(the reference runs one ccoherent thread); reference itself unbuildable here (VOLK/FFTW absent)",
             "allcores": {"value": nbm / dtm, "cores": nthreads, "sample": f"{nbm} blocks, rows split over {nthreads} pthreads"}}
