@@ -251,8 +251,25 @@ __device__ __forceinline__ void xcorr_row14(const XcorrArgs &a, unsigned char *s
     __syncthreads();
     int gi = redi[16];
     if ((unsigned)gi >= (unsigned)N) gi = 0; // all-NaN row: defined as index 0
-    // neighbours of the peak for the parabolic estimate: their owners publish them
-    {
+    // neighbours of the peak for the parabolic estimate.  gi = i*512 + c: its neighbours are the same output i of the
+    // columns c -+ 1, i.e. the adjacent lanes of the owner's wave unless the owner sits on a wave edge -- then (1 row in
+    // 32) they go through LDS and one more barrier, otherwise the owner's wave finishes the row on its own
+    const int pc = gi & 511, pi_ = gi >> 9;
+    const bool in_wave = ((pc & 63) != 0) && ((pc & 63) != 63);       // workgroup-uniform
+    if (in_wave) {
+        if ((tid >> 6) == (pc >> 6)) {
+            float mine = 0.f;
+#pragma unroll
+            for (int i = 0; i < 32; ++i) mine = (i == pi_) ? m[i] : mine;
+            const float ym = __shfl_up(mine, 1, 64), yp = __shfl_down(mine, 1, 64);
+            if (tid == pc) {
+                float D = 0.0f;
+                const float den = (ym - 2.0f * gm) + yp;
+                if (den != 0.0f) D = (0.5f * (ym - yp)) / den;
+                xcorr_publish(a, row, t, gi - L /* src/ccoherent.cc:232 */, sqrtf(gm / (float)L) * kInvScale2 /* :204 */, D);
+            }
+        }
+    } else {
         const int nl = gi - 1, nr = gi + 1;
         if (gi > 0 && (nl & 511) == tid) {
             float ml = 0.f;
@@ -266,16 +283,16 @@ __device__ __forceinline__ void xcorr_row14(const XcorrArgs &a, unsigned char *s
             for (int i = 0; i < 32; ++i) mr = (i == (nr >> 9)) ? m[i] : mr;
             red[33] = mr;
         }
-    }
-    __syncthreads();
-    if (tid == 0) {
-        float D = 0.0f;
-        if (gi > 0 && gi < N - 1) {
-            const float ym = red[32], yp = red[33];
-            const float den = (ym - 2.0f * gm) + yp;
-            if (den != 0.0f) D = (0.5f * (ym - yp)) / den;
+        __syncthreads();
+        if (tid == 0) {
+            float D = 0.0f;
+            if (gi > 0 && gi < N - 1) {
+                const float ym = red[32], yp = red[33];
+                const float den = (ym - 2.0f * gm) + yp;
+                if (den != 0.0f) D = (0.5f * (ym - yp)) / den;
+            }
+            xcorr_publish(a, row, t, gi - L /* src/ccoherent.cc:232 */, sqrtf(gm / (float)L) * kInvScale2 /* :204 */, D);
         }
-        xcorr_publish(a, row, t, gi - L /* src/ccoherent.cc:232 */, sqrtf(gm / (float)L) * kInvScale2 /* :204 */, D);
     }
     CRSDR_STAMP(8);
 }
