@@ -302,7 +302,7 @@ __device__ __forceinline__ uint32_t rotq_word(uint32_t s, float2 p)
 {
     // On packed pairs (cpk.hpp): per sample  x = (I, Q) * (1/127)  [v_pk_mul],  t1 = x * p.x, t2 = (Q, I) * p.y  [2 v_pk_mul],
     // y = (t1.x - t2.x, t1.y + t2.y)  [v_pk_add, neg_lo] -- the four products and two sums of rot_rn, each rounded once --
-    // then y * 127 [v_pk_mul], clamp, round-half-even, and  +128 -> v_cvt_pk_u8_f32 (exact on integers in [0, 255])
+    // then y * 127 [v_pk_mul], round-half-even, and  +128 -> v_cvt_pk_u8_f32 (saturating to [0, 255] = the clamp)
     // straight into the byte lane; one XOR turns the four offset-binary bytes back into two's complement.
     const c2 pp = c2{p.x, p.y};
     uint32_t out = 0u;
@@ -315,8 +315,9 @@ __device__ __forceinline__ uint32_t rotq_word(uint32_t s, float2 p)
         asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[0,1]" : "=v"(t2) : "v"(x), "v"(pp));                     // (Q py, I py)
         asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1]" : "=v"(y) : "v"(t1), "v"(t2));                                    // (I px - Q py, Q px + I py)
         y = y * 127.0f;
-        const float r0 = rintf(__builtin_amdgcn_fmed3f(y.x, -128.0f, 127.0f)), r1 = rintf(__builtin_amdgcn_fmed3f(y.y, -128.0f, 127.0f));
-        const c2 u = c2{r0, r1} + 128.0f;
+        // round first, then let v_cvt_pk_u8_f32 saturate: rint(clamp(x)) == clamp(rint(x)) on [-128, 127] (ties to even keep
+        // 127.5 -> 128 -> 127 and -128.5 -> -128), and r + 128 is exact, so the explicit clamp of cdsp::convto8bit is implied
+        const c2 u = c2{rintf(y.x), rintf(y.y)} + 128.0f;
         asm("v_cvt_pk_u8_f32 %0, %1, %2, %0" : "+v"(out) : "v"(u.x), "n"(2 * h));
         asm("v_cvt_pk_u8_f32 %0, %1, %2, %0" : "+v"(out) : "v"(u.y), "n"(2 * h + 1));
     }
