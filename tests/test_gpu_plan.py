@@ -578,3 +578,30 @@ def test_phase_path_variants_are_bit_identical(tmp_path):
     for other in ("fallback", "three", "overlap"):
         for key in ("phasor", "packet", "lag", "mag"):
             assert np.array_equal(outs["fused"][key].view(np.uint8), outs[other][key].view(np.uint8)), (other, key)
+
+
+def test_rotate_quantise_saturates_like_convto8bit(b, oracle):
+    # full-scale samples rotated by ~45 degrees exceed the int8 range (127 * sqrt 2): cdsp::convto8bit clamps to
+    # [-128, 127] before rounding (src/cdsp.cc:51-54); the phase kernels round and let the byte conversion saturate.
+    # Bit-exact against the oracle's ops fed with the GPU's own phasor, including ties at x.5.
+    L = 2048
+    rng = np.random.default_rng(8)
+    rows = np.zeros((4, 2 * L), dtype=np.int8)
+    ref = rng.integers(-100, 100, size=2 * L).astype(np.int8)
+    rows[0] = ref
+    ang = np.pi / 4
+    x = (ref[0::2].astype(np.float64) + 1j * ref[1::2]) * np.exp(1j * ang)          # a rotated copy: phasor -> e^{-j pi/4}
+    rows[1, 0::2] = np.clip(np.rint(x.real), -128, 127); rows[1, 1::2] = np.clip(np.rint(x.imag), -128, 127)
+    rows[2] = rows[1]; rows[2, :64] = 127; rows[2, 64:128] = -128                     # full-scale corners
+    rows[3] = rows[1]; rows[3, 0:256:2] = 127; rows[3, 1:256:2] = -128
+    plan = b.Plan(4, 2 * L, b.MODE_FAITHFUL)
+    for t in range(6):
+        got = plan.block(rows, seq=t)
+    sat = 0
+    for r in range(1, 4):
+        y = oracle.scalarmul(oracle.convtofloat(rows[r]), got["phasor"][r])
+        exp = oracle.convto8bit(y)
+        assert np.array_equal(exp, got["matrix"][r]), r
+        sat += int(np.count_nonzero((exp == 127) | (exp == -128)))
+    assert sat > 50                                   # the case really saturates
+    plan.close()
