@@ -51,6 +51,7 @@ int main(int argc, char **argv)
     int nsig = 3, L = 8192, blocks = 12, mode = CRSDR_MODE_DIGITAL, dmax = -1;
     std::string dump, zmqaddr;
     bool run_cdsp = false, servo = false, threads = false, music = false;
+    std::string replay;
     int pace_ms = 0;
     for (int i = 1; i < argc; ++i) {
         std::string a = argv[i];
@@ -67,6 +68,7 @@ int main(int argc, char **argv)
         else if (a == "--zmq" && i + 1 < argc) zmqaddr = argv[++i];           // e.g. tcp://127.0.0.1:5555 (reference: tcp://*:5555)
         else if (a == "--zmq-debug" && i + 1 < argc) cpacketize::debugaddress = argv[++i];
         else if (a == "--pace-ms") val(pace_ms);
+        else if (a == "--replay" && i + 1 < argc) { replay = argv[++i]; threads = true; }   // <prefix><row>.u8: raw uint8 IQ recordings (f2)
         else if (a == "--music") music = true;      // f4: the last packet through the beamformer chain (needs nsig = 7 x 3)
     }
     int fails = 0;
@@ -102,8 +104,15 @@ int main(int argc, char **argv)
             ++npk;
         };
         const int pace_us = pace_ms ? pace_ms * 1000 : 3000;
-        ref.start(pace_us, blocks);
-        for (auto &d : own) d->start(pace_us, blocks);
+        if (!replay.empty()) {
+            // recorded streams: one raw offset-binary uint8 file per channel, row 0 = the reference-noise channel
+            bool ok = ref.start_replay((replay + "0.u8").c_str(), pace_us, blocks);
+            for (int k = 0; k < nsig; ++k) ok = own[k]->start_replay((replay + std::to_string(1 + k) + ".u8").c_str(), pace_us, blocks) && ok;
+            if (!ok) { std::printf("DEMO FAILED\n"); return 1; }
+        } else {
+            ref.start(pace_us, blocks);
+            for (auto &d : own) d->start(pace_us, blocks);
+        }
         coherent.start();
         for (int t = 0; t < blocks; ++t) cpacketize::send();
         coherent.request_exit();
@@ -111,7 +120,10 @@ int main(int argc, char **argv)
         for (auto &d : own) d->stop();
         coherent.join();
         const csynth_params *p = source.get_params();
-        for (int k = 0; k < nsig; ++k) fails += ((long)devs[k]->get_lagp()->lag != (long)p->d[k]);
+        for (int k = 0; k < nsig; ++k) {
+            if (!replay.empty()) std::printf("row %d: lag %ld\n", 1 + k, (long)devs[k]->get_lagp()->lag);   // the recording's truth is the caller's
+            else fails += ((long)devs[k]->get_lagp()->lag != (long)p->d[k]);
+        }
         uint32_t over = ref.get_overruns();
         for (auto &d : own) over += d->get_overruns();
         std::printf("streaming: %zu packets, %zu readcnt gaps, %u ring overruns, lags %s\n", npk, gaps, over, fails ? "MISMATCH" : "ok");

@@ -97,7 +97,12 @@ void csyntheticsdr::asynch_threadf(csyntheticsdr *d)
     // (src/crtlsdr.cc:61-68,173-193, include/common.h:114-122), here fed by the synthetic source
     std::vector<int8_t> tmp(d->blocksize);
     for (int t = 0; (d->max_blocks == 0 || t < d->max_blocks) && !d->do_exit; ++t) {
-        csynth_make_row(d->src->get_params(), t, d->rowindex, -1.0, tmp.data());
+        if (d->replay) {
+            if (std::fread(tmp.data(), 1, d->blocksize, d->replay) != d->blocksize) break;   // end of the recording
+            for (uint32_t i = 0; i < d->blocksize; ++i) tmp[i] = (int8_t)((uint8_t)tmp[i] ^ 0x80u); // the ring store below re-applies it
+        } else {
+            csynth_make_row(d->src->get_params(), t, d->rowindex, -1.0, tmp.data());
+        }
         {
             std::unique_lock<std::mutex> lock(d->mtx);
             if (d->ring->backlog() >= d->ring->capacity()) {  // consumer too slow: the oldest block is lost (README.md:42)
@@ -125,11 +130,20 @@ void csyntheticsdr::start(int pace_us_, int max_blocks_)
     producer = std::thread(asynch_threadf, this);
 }
 
+bool csyntheticsdr::start_replay(const char *path, int pace_us_, int max_blocks_)
+{
+    replay = std::fopen(path, "rb");
+    if (!replay) { std::fprintf(stderr, "%s: cannot open %s\n", devname.c_str(), path); return false; }
+    start(pace_us_, max_blocks_);
+    return true;
+}
+
 void csyntheticsdr::stop()
 {
     do_exit = true;
     cv.notify_all();
     if (producer.joinable()) producer.join();
+    if (replay) { std::fclose(replay); replay = nullptr; }
 }
 
 void csyntheticsdr::advance_resampler()

@@ -9,6 +9,7 @@
 #include <atomic>
 #include <chrono>
 #include <complex>
+#include <cstdio>
 #include <condition_variable>
 #include <cstdint>
 #include <memory>
@@ -130,6 +131,7 @@ protected:
     std::atomic<bool> do_exit{false};
     uint32_t cur_rcnt = 0, produced = 0, overruns = 0;
     int pace_us = 0, max_blocks = 0;
+    FILE *replay = nullptr;
     static void asynch_threadf(csyntheticsdr *d);
     // resampler model (ccontrol): accumulated slip in samples while a correction is set
     float correction = 0.0f;
@@ -141,6 +143,11 @@ public:
     void consume() override;
     uint32_t get_readcntbuf() override { return ring ? cur_rcnt : get_readcnt(); }
     void start(int pace_us_, int max_blocks_);          // crtlsdr::start src/crtlsdr.cc:24-30
+    // Replay a recording instead of synthesising: `path` holds this channel's raw offset-binary uint8 IQ stream,
+    // exactly what librtlsdr's callback delivers and `rtl_sdr -f ... file` writes; one ring block per blocksize bytes,
+    // the producer stops at end of file.  (The reference's hardware-free device is the empty czmqsdr stub,
+    // include/csdrdevice.h:270-272.)
+    bool start_replay(const char *path, int pace_us_, int max_blocks_);
     void stop();                                        // :36-42
     bool is_streaming_raw() const { return (bool)ring; } // rows are raw uint8 (offset binary) in streaming mode
     uint32_t get_overruns() const { return overruns; }
