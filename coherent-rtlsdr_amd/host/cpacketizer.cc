@@ -54,9 +54,13 @@ cpacketize::sink_t cpacketize::sink;
 cpacketize::cpacketize() { objcount++; }                     // src/cpacketizer.cc:45-51
 cpacketize::~cpacketize() { objcount--; }
 
+bool cpacketize::refpadding = false;
 size_t cpacketize::packetlength(uint32_t N, uint32_t L)
 {
-    return noheader ? (size_t)N * L : (16 + 4 * (size_t)N) + (size_t)N * L;
+    // L = blocksize in int8 values.  The reference sizes the message 2*N*L data bytes (src/cpacketizer.cc:95, it counts
+    // complex samples twice) and sends all of it; with refpadding the same length goes on the wire, the tail zero
+    const size_t data = (size_t)N * L * (refpadding ? 2 : 1);
+    return noheader ? data : (16 + 4 * (size_t)N) + data;
 }
 
 void cpacketize::resize_buffers(uint32_t N, uint32_t L)

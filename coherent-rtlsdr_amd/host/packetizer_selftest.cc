@@ -22,6 +22,7 @@ int main(int argc, char **argv)
         else if (a == "--pace-ms") pace_ms = atoi(argv[i + 1]);
         else if (a == "--zmq") addr = argv[i + 1];
         else if (a == "--zmq-debug") cpacketize::debugaddress = argv[i + 1];
+        else if (a == "--refpadding") cpacketize::refpadding = atoi(argv[i + 1]) != 0;   // the reference's 2x data length on the wire
     }
     const uint32_t B = 2 * (uint32_t)L, N = 1 + (uint32_t)nsig;
     std::vector<cpacketize> channels(N);               // one cpacketize member per device (src/csdrdevice.cc:20-48)

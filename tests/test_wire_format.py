@@ -118,6 +118,31 @@ def test_packetizer_publishes_reference_wire_format(host_build, synth):
         assert ph.size == nsig + 1 and np.array_equal(ph.real, np.arange(nsig + 1))
 
 
+def test_reference_message_length_option(host_build, synth):
+    # the reference sends 16 + 4N + 2*N*B bytes per message (src/cpacketizer.cc:95,125: it doubles the data size), of
+    # which clients parse the first N*B data bytes (matlabclient/zmqsdr.c:121-143); cpacketize::refpadding reproduces
+    # that length with a zero tail for consumers that size their buffers by it
+    z = _libzmq()
+    nsig, L, blocks = 2, 128, 25
+    addr, dbg = f"tcp://127.0.0.1:{_free_port()}", f"tcp://127.0.0.1:{_free_port()}"
+    sub = Subscriber(z, addr, 1 << 20, 3)
+    sub.start()
+    time.sleep(0.2)
+    r = subprocess.run([os.path.join(host_build, "packetizer_selftest"), "--nsig", str(nsig), "--L", str(L), "--blocks", str(blocks),
+                        "--zmq", addr, "--zmq-debug", dbg, "--refpadding", "1"], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 0, r.stderr
+    sub.join(10)
+    assert len(sub.msgs) >= 3
+    N, B = nsig + 1, 2 * L
+    params = synth.RowParams(nsig, L, 4242, dmax=L // 8)
+    for m in sub.msgs:
+        assert len(m) == 16 + 4 * N + 2 * N * B
+        gseq, c, rr, seqs, data, _ = _parse_like_zmqsdr_c(m)
+        rows, _ = synth.make_block(nsig, L, 4242, gseq, params=params)
+        assert (c, rr) == (N, L) and np.array_equal(data, rows)
+        assert not any(m[16 + 4 * N + N * B:])                 # the tail is zero
+
+
 @pytest.mark.gpu
 def test_engine_publishes_aligned_matrix_over_zmq(host_build, synth):
     # full chain on the GPU box: csyntheticsdr -> ccoherent::step (libcrsdr plan) -> cpacketize::send -> ZMQ SUB
