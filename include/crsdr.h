@@ -209,7 +209,9 @@ size_t crsdr_plan_packet_stride(const crsdr_plan *plan);  /* bytes between the p
 
 /* Device-resident results for pipelines that never leave HBM (multi-GPU gather, benchmarks).
  * The packet pointer is 4-byte aligned and the matrix inside it 256-byte aligned; per-row arrays
- * are [max_batch][nrows] (block t of the last batch at + t * nrows). */
+ * are [max_batch][nrows] (block t of the last batch at + t * nrows).  lag / mag / frac alternate between two
+ * such arrays from submit to submit: call this after the submit whose results are wanted; the pointers stay valid
+ * (and unmodified) until the submit after the next one. */
 int crsdr_plan_device_buffers(crsdr_plan *plan, void **packet, void **lag, void **mag,
                               void **frac, void **phasor);
 /* Write the packets of later submits into a caller-owned device buffer instead: block t of a
