@@ -7,6 +7,9 @@ C oracle and the HIP path against a fixed, reviewable set of numbers:
 
   cfg1_{faithful,digital}.npz : config 1 shape (1 ref + 3 signal rows x 8192, four.cfg), 3 blocks
   small_digital.npz           : 1 + 5 rows x 512 samples (B = 1024), 4 blocks, digital mode
+  long_digital.npz            : 1 + 2 rows x 32768 samples (B = 65536: the long-block path), 2 blocks, digital mode
+  music_ura21.npz             : the beamformer chain on a 7 x 3 URA scene: rows, covariance, singular
+                                values, noise-subspace projector and the 40 x 40 MUSIC map, fp64 numpy model (tests/ura.py)
 
 Run:  python tests/golden/make_golden.py   (from the repo root)
 """
@@ -46,3 +49,13 @@ if __name__ == "__main__":
     gen("cfg1_faithful", 3, 8192, 1, M.FAITHFUL, 3)
     gen("cfg1_digital", 3, 8192, 1, M.DIGITAL, 3)
     gen("small_digital", 5, 512, 101, M.DIGITAL, 4, dmax=100)
+    gen("long_digital", 2, 1 << 15, 102, M.DIGITAL, 2, dmax=3000)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import ura  # noqa: E402
+    rng = np.random.default_rng(2024)
+    rows = ura.scene(4096, [(0.8, 1.7, 1.0), (2.1, 0.9, 0.6)], rng)
+    R, U, s, pm = ura.music_fp64(rows, 2, ncx=40, ncy=40)
+    Un = U[:, 2:]
+    np.savez_compressed(os.path.join(HERE, "music_ura21.npz"), rows=rows, rxx=R, sv=s, projector=Un @ Un.conj().T, pm=pm,
+                        k=np.int32(2), d=np.float32(ura.D), mx=np.int32(ura.MX), my=np.int32(ura.MY))
+    print("music_ura21 sv", s[:4])

@@ -108,3 +108,16 @@ def test_calibrate_freeze_then_locate_a_source(b):
     pm0 = b.pmusic2d(vec0, 1, ura.D, ura.MX, ura.MY)
     assert pm0[cx, cy] < 0.01 * pm[cx, cy]
     plan.close()
+
+
+def test_music_chain_matches_the_committed_fixture(b, golden_dir):
+    import os
+    g = np.load(os.path.join(golden_dir, "music_ura21.npz"))
+    k = int(g["k"])
+    rxx = b.covariance(g["rows"])
+    assert np.abs(rxx - g["rxx"]).max() <= 2e-6 * np.abs(g["rxx"]).max()
+    vec, sv = b.noisesubspace(rxx)
+    assert np.allclose(sv, g["sv"], rtol=1e-5, atol=1e-7)
+    assert np.abs(_projector(vec, k) - g["projector"]).max() < 1e-5
+    pm = b.pmusic2d(vec, k, float(g["d"]), int(g["mx"]), int(g["my"]), 40, 40)
+    assert np.allclose(pm, g["pm"], rtol=1e-2)

@@ -54,7 +54,7 @@ def _compare_model(got, mod):
     assert np.abs(d).max() <= 1 and np.count_nonzero(d) <= 1e-3 * d.size
 
 
-@pytest.mark.parametrize("name", ["cfg1_faithful", "cfg1_digital", "small_digital"])
+@pytest.mark.parametrize("name", ["cfg1_faithful", "cfg1_digital", "small_digital", "long_digital"])
 def test_plan_matches_golden_and_oracle(b, oracle, golden_dir, name):
     g = np.load(os.path.join(golden_dir, name + ".npz"))
     nblocks, nrows, B = g["rows"].shape
@@ -63,7 +63,7 @@ def test_plan_matches_golden_and_oracle(b, oracle, golden_dir, name):
     for t in range(nblocks):
         got = plan.block(g["rows"][t], seq=t, readcnt=np.arange(nrows) + 10 * t)
         exp = orc.block(g["rows"][t], seq=t, readcnt=np.arange(nrows) + 10 * t)
-        _compare(got, exp)
+        _compare(got, exp, phase_tol=1e-5 if B <= 16384 else 1e-4)    # long rows: the oracle's fp32 accumulator, see _compare
         # committed fp64 golden
         assert np.array_equal(got["lag"], g["lag"][t])
         assert np.allclose(got["mag"], g["mag"][t], rtol=1e-4)

@@ -25,7 +25,7 @@ def _check_block(out, g, t, nrows):
     assert np.array_equal(out["matrix"][0], g["rows"][t][0])   # raw ref row, src/cpacketizer.cc:151
 
 
-@pytest.mark.parametrize("name", ["cfg1_faithful", "cfg1_digital", "small_digital"])
+@pytest.mark.parametrize("name", ["cfg1_faithful", "cfg1_digital", "small_digital", "long_digital"])
 def test_engine_matches_golden(oracle, golden_dir, name):
     g = _load(golden_dir, name)
     nblocks, nrows, B = g["rows"].shape

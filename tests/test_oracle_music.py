@@ -45,3 +45,17 @@ def test_oracle_subspace_of_rank_deficient_and_small_matrices(oracle):
     R2 = np.array([[2, 1j], [-1j, 2]], dtype=np.complex64)
     vec, sv = oracle.noisesubspace(R2)
     assert np.allclose(sv, [3, 1], atol=1e-6)
+
+
+def test_oracle_music_chain_matches_the_committed_fixture(oracle, golden_dir):
+    # tests/golden/music_ura21.npz: two sources on the 7 x 3 URA, fp64 numpy chain (tests/golden/make_golden.py)
+    import os
+    g = np.load(os.path.join(golden_dir, "music_ura21.npz"))
+    k = int(g["k"])
+    rxx = oracle.covariance(g["rows"])
+    assert np.abs(rxx - g["rxx"]).max() <= 1e-6 * np.abs(g["rxx"]).max()
+    vec, sv = oracle.noisesubspace(rxx)
+    assert np.allclose(sv, g["sv"], rtol=1e-5, atol=1e-7)
+    assert np.abs(_projector(vec, k) - g["projector"]).max() < 1e-5
+    pm = oracle.pmusic2d(vec, k, float(g["d"]), int(g["mx"]), int(g["my"]), 40, 40)
+    assert np.allclose(pm, g["pm"], rtol=5e-3)
