@@ -1032,7 +1032,8 @@ extern "C" int crsdr_plan_submit_batch(crsdr_plan *p, const void *rows, int mem_
         hipEvent_t *pe = prof_pair(p, CRSDR_KERNEL_ALIGN_QUANT);
         if (pe) HIP_TRY(hipEventRecord(pe[0], S));
         if (aa.refnoise && nblocks > 1) HIP_TRY(hipMemsetAsync(p->d_corr, 0xFF, sizeof(long long) * 2 * n * T, S)); // re-arm the chain
-        hipLaunchKernelGGL(k_align_fused, dim3((unsigned)((1 + p->row_count) * nblocks)), dim3(kAlignThreads), 0, S, aa, fs);
+        if (p->B == 16384) hipLaunchKernelGGL(k_align_fused<true>, dim3((unsigned)((1 + p->row_count) * nblocks)), dim3(kAlignThreads), 0, S, aa, fs);
+        else hipLaunchKernelGGL(k_align_fused<false>, dim3((unsigned)((1 + p->row_count) * nblocks)), dim3(kAlignThreads), 0, S, aa, fs);
         HIP_TRY(hipGetLastError());
         if (pe) HIP_TRY(hipEventRecord(pe[1], S));
         HIP_TRY(hipEventRecord(p->ev_k2done[obuf], S));

@@ -456,6 +456,8 @@ struct FusedSync {
 constexpr unsigned long long kChainEmpty = ~0ull;
 constexpr int kFusedSpinLimit = 2048;      // polls of ~1 us each before a workgroup stops waiting and computes the value itself
 
+// FULL: B == 16384, every thread owns exactly four 16-byte vectors of the row (no bounds checks in the hot loops)
+template <bool FULL>
 __global__ __launch_bounds__(kAlignThreads, 8) void k_align_fused(AlignArgs a, FusedSync fs)
 {
     __shared__ long long sred[2 * (kAlignThreads / 64)];
@@ -465,7 +467,7 @@ __global__ __launch_bounds__(kAlignThreads, 8) void k_align_fused(AlignArgs a, F
     const unsigned int per = (unsigned)fs.row_count + 1u;
     const unsigned int ticket = blockIdx.x;
     const int t = (int)(ticket / per), x = (int)(ticket % per);
-    const int B = a.B, L = B >> 1, nvec = B / 16;
+    const int B = FULL ? 16384 : a.B, L = B >> 1, nvec = B / 16;
     const size_t moff = 16 + 4 * (size_t)a.nrows;
     const int8_t *blk = a.rows + (size_t)t * a.block_stride;
     int8_t *packet = a.packet + (size_t)t * a.packet_stride;
@@ -495,7 +497,7 @@ __global__ __launch_bounds__(kAlignThreads, 8) void k_align_fused(AlignArgs a, F
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const int i = tid + q * kAlignThreads;
-        sv[q] = (i < nvec) ? shifted_vec(srow, i, d, L, a.xor80) : make_uint4(0u, 0u, 0u, 0u);
+        sv[q] = (FULL || i < nvec) ? shifted_vec(srow, i, d, L, a.xor80) : make_uint4(0u, 0u, 0u, 0u);
     }
     if (a.refnoise) {
         const uint4 *r128 = reinterpret_cast<const uint4 *>(blk);
@@ -503,7 +505,7 @@ __global__ __launch_bounds__(kAlignThreads, 8) void k_align_fused(AlignArgs a, F
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int i = tid + q * kAlignThreads;
-            if (i < nvec) {
+            if (FULL || i < nvec) {
                 const uint4 rv = r128[i];
                 dot_word(sv[q].x, rv.x ^ a.xor80, re, im);
                 dot_word(sv[q].y, rv.y ^ a.xor80, re, im);
@@ -621,7 +623,7 @@ __global__ __launch_bounds__(kAlignThreads, 8) void k_align_fused(AlignArgs a, F
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const int i = tid + q * kAlignThreads;
-        if (i < nvec) o128[i] = make_uint4(rotq_word(sv[q].x, p), rotq_word(sv[q].y, p), rotq_word(sv[q].z, p), rotq_word(sv[q].w, p));
+        if (FULL || i < nvec) o128[i] = make_uint4(rotq_word(sv[q].x, p), rotq_word(sv[q].y, p), rotq_word(sv[q].z, p), rotq_word(sv[q].w, p));
     }
 }
 
