@@ -493,24 +493,53 @@ __global__ __launch_bounds__(kAlignThreads, 8) void k_align_fused(AlignArgs a, F
     const size_t o = (size_t)t * a.nrows + row;
     const int d = align_shift(a, row, t);
     const int8_t *srow = blk + (size_t)row * B;
-    uint4 sv[4];
+    // All eight 16-byte loads of a thread (its four row vectors and the reference row's) are issued back to back
+    // with no branch between them: an interior vector is ONE load at a 2-byte-aligned address, and a vector that
+    // straddles or lies outside [0,L) loads from the row start instead and is patched afterwards (rare: at most two
+    // straddle; a branch around each load would make the compiler wait for one before issuing the next).
+    uint4 sv[4], rv[4];
+    bool edge = false;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const int i = tid + q * kAlignThreads;
-        sv[q] = (FULL || i < nvec) ? shifted_vec(srow, i, d, L, a.xor80) : make_uint4(0u, 0u, 0u, 0u);
+        const int m0 = 8 * i + d;
+        const bool inside = (FULL || i < nvec) && m0 >= 0 && m0 + 8 <= L;
+        const u4_unaligned u = *reinterpret_cast<const u4_unaligned *>(srow + 2 * (ptrdiff_t)(inside ? m0 : 0));
+        sv[q] = make_uint4(u.x, u.y, u.z, u.w);
+        edge |= !inside;
     }
     if (a.refnoise) {
         const uint4 *r128 = reinterpret_cast<const uint4 *>(blk);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int i = tid + q * kAlignThreads;
+            rv[q] = r128[(FULL || i < nvec) ? i : 0];
+        }
+    }
+    if (edge) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int i = tid + q * kAlignThreads;
+            const int m0 = 8 * i + d;
+            if (!FULL && i >= nvec) sv[q] = make_uint4(a.xor80, a.xor80, a.xor80, a.xor80);
+            else if (!(m0 >= 0 && m0 + 8 <= L)) {
+                const uint4 e = shifted_vec(srow, i, d, L, a.xor80);
+                sv[q] = make_uint4(e.x ^ a.xor80, e.y ^ a.xor80, e.z ^ a.xor80, e.w ^ a.xor80);
+            }
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) sv[q] = make_uint4(sv[q].x ^ a.xor80, sv[q].y ^ a.xor80, sv[q].z ^ a.xor80, sv[q].w ^ a.xor80);
+    if (a.refnoise) {
         int re = 0, im = 0;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int i = tid + q * kAlignThreads;
             if (FULL || i < nvec) {
-                const uint4 rv = r128[i];
-                dot_word(sv[q].x, rv.x ^ a.xor80, re, im);
-                dot_word(sv[q].y, rv.y ^ a.xor80, re, im);
-                dot_word(sv[q].z, rv.z ^ a.xor80, re, im);
-                dot_word(sv[q].w, rv.w ^ a.xor80, re, im);
+                dot_word(sv[q].x, rv[q].x ^ a.xor80, re, im);
+                dot_word(sv[q].y, rv[q].y ^ a.xor80, re, im);
+                dot_word(sv[q].z, rv[q].z ^ a.xor80, re, im);
+                dot_word(sv[q].w, rv[q].w ^ a.xor80, re, im);
             }
         }
         long long acc_re = re, acc_im = im;
