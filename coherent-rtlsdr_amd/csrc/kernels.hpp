@@ -451,7 +451,7 @@ struct FusedSync {
     unsigned int *status;              // [0] number of look-back waits that ran out and were computed locally
     unsigned long long *chain;         // [T][nrows][2]: [0] = phasor bits or all-ones
     int row_count;
-    int spin_limit;                    // polls before the local fallback (kFusedSpinLimit; tests force 0)
+    int spin_limit;                    // polls before the local fallback (kFusedSpinLimit); < 0: treat every earlier block as missing (tests)
 };
 constexpr unsigned long long kChainEmpty = ~0ull;
 constexpr int kFusedSpinLimit = 2048;      // polls of ~1 us each before a workgroup stops waiting and computes the value itself
@@ -528,6 +528,16 @@ __global__ __launch_bounds__(kAlignThreads, 8) void k_align_fused(AlignArgs a, F
             }
         }
     }
+    // wave 0 also starts what the fold will need -- the carried phasor and the unit phasors that earlier blocks of
+    // this row have already published -- so that their latency hides behind the row loads instead of following them
+    float2 p_in = make_float2(0.f, 0.f);
+    unsigned long long bits = 0ull;          // wave 0, lane u <= t: unit phasor of block u of this row
+    if (tid < 64) {
+        p_in = a.phase_in[row];
+        if (a.refnoise && tid < t)
+            bits = fs.spin_limit < 0 ? kChainEmpty
+                                     : __hip_atomic_load(fs.chain + 2 * ((size_t)tid * a.nrows + row), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
 #pragma unroll
     for (int q = 0; q < 4; ++q) sv[q] = make_uint4(sv[q].x ^ a.xor80, sv[q].y ^ a.xor80, sv[q].z ^ a.xor80, sv[q].w ^ a.xor80);
     if (a.refnoise) {
@@ -558,7 +568,6 @@ __global__ __launch_bounds__(kAlignThreads, 8) void k_align_fused(AlignArgs a, F
         const double inv = 1.0 / sqrt(cr * cr + ci * ci);
         return (unsigned long long)__float_as_uint((float)(cr * inv)) | ((unsigned long long)__float_as_uint((float)(-ci * inv)) << 32);
     };
-    unsigned long long bits = 0ull;          // wave 0, lane u <= t: unit phasor of block u of this row
     if (tid < 64) {
         if (tid == 0 && !a.xcorr_ran) {   // no lag measured in this batch: republish the carried one (include/csdrdevice.h:161)
             a.lag_out[o] = a.lag_state[row]; a.mag_out[o] = a.mag_state[row]; a.frac_out[o] = a.frac_state[row];
@@ -572,15 +581,14 @@ __global__ __launch_bounds__(kAlignThreads, 8) void k_align_fused(AlignArgs a, F
                 mine = unit_bits(sr, si);
                 __hip_atomic_store(fs.chain + 2 * o, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
-            // lane u < t fetches the unit phasor of block u (published right after that block's dot product, long
-            // before its own rotation); lane t takes this block's
+            // lane u < t holds the unit phasor of block u (published right after that block's dot product, long
+            // before its own rotation) from the prefetch above, or polls for it now; lane t takes this block's
             if (tid < t) {
                 unsigned long long *src = fs.chain + 2 * ((size_t)tid * a.nrows + row);
-                bits = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 int spins = 0;
                 while (bits == kChainEmpty && spins < fs.spin_limit) {
-                    __builtin_amdgcn_s_sleep(8);
                     bits = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (bits == kChainEmpty) __builtin_amdgcn_s_sleep(8);
                     ++spins;
                 }
             }
@@ -627,13 +635,15 @@ __global__ __launch_bounds__(kAlignThreads, 8) void k_align_fused(AlignArgs a, F
         __syncthreads();
     }
     if (tid < 64) {
-        float2 p = a.phase_in[row];
+        float2 p = p_in;
         if (a.refnoise) {
             if (tid < t && bits == kChainEmpty) bits = sfix[tid];
+            const int blo = (int)(unsigned)(bits & 0xffffffffull), bhi = (int)(unsigned)(bits >> 32);
             for (int u = 0; u <= t; ++u) {     // one sequential fold in block order (src/csdrdevice.cc:66-67)
-                const unsigned long long b = __shfl(bits, u, 64);
-                if (b != 0ull) {
-                    const float pr = __uint_as_float((unsigned)(b & 0xffffffffull)), pi = __uint_as_float((unsigned)(b >> 32));
+                // u is wave-uniform: v_readlane into scalar registers, not a trip through the LDS crossbar
+                const unsigned rl = (unsigned)__builtin_amdgcn_readlane(blo, u), rh = (unsigned)__builtin_amdgcn_readlane(bhi, u);
+                if ((rl | rh) != 0u) {
+                    const float pr = __uint_as_float(rl), pi = __uint_as_float(rh);
                     p = make_float2(__fadd_rn(__fmul_rn(0.5f, pr), __fmul_rn(0.5f, p.x)),
                                     __fadd_rn(__fmul_rn(0.5f, pi), __fmul_rn(0.5f, p.y)));
                 }

@@ -569,7 +569,7 @@ def test_phase_path_variants_are_bit_identical(tmp_path):
                  lag=np.stack([r["lag"] for r in res]), mag=np.stack([r["mag"] for r in res]))
     ''') % root
     outs = {}
-    for name, env in (("fused", {}), ("fallback", {"CRSDR_K2_SPIN": "0"}), ("three", {"CRSDR_K2_FUSED": "0"}),
+    for name, env in (("fused", {}), ("fallback", {"CRSDR_K2_SPIN": "-1"}), ("three", {"CRSDR_K2_FUSED": "0"}),
                       ("overlap", {"CRSDR_OVERLAP": "1"})):            # K1 of the next batch beside this batch's phase kernel
         out = tmp_path / f"{name}.npz"
         r = subprocess.run([sys.executable, "-c", code, str(out)], env=dict(os.environ, **env), capture_output=True, text=True, timeout=300)
