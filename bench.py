@@ -269,9 +269,13 @@ def main():
     if not args.no_extras:
         fl_locked = flags | b.NO_LAG
         run_steps(2 * T, fl_locked)
-        plan.enable_profiling(256, (1 << b.KERNEL_PHASE_DOT) | (1 << b.KERNEL_ALIGN_QUANT))
-        n_l = max(args.steps, 200) // T * T
+        # the rate is timed without per-kernel events over >= 16 batches (a batch is ~0.6 ms: a shorter region would
+        # mostly measure its own fences); the kernel's launch duration comes from a separate short profiled run
+        n_l = max(args.steps, 16 * T) // T * T
         dt_l = timed(n_l, fl_locked)
+        plan.enable_profiling(256, (1 << b.KERNEL_PHASE_DOT) | (1 << b.KERNEL_ALIGN_QUANT))
+        run_steps(4 * T, fl_locked)
+        fence()
         k2 = plan.kernel_times_ms(b.KERNEL_ALIGN_QUANT)
         k2a = plan.kernel_times_ms(b.KERNEL_PHASE_DOT)
         plan.enable_profiling(0)

@@ -1006,7 +1006,8 @@ extern "C" int crsdr_plan_submit_batch(crsdr_plan *p, const void *rows, int mem_
         XcorrArgs xa;
         xa.rows = d_in; xa.block_stride = d_stride; xa.refspec = p->d_refspec[slot]; xa.lag_mask = d_mask;
         xa.row_begin = p->row_begin; xa.nrows = p->nrows; xa.nblocks = nblocks; xa.xor80 = xor80;
-        { const char *sg = getenv("CRSDR_K1_STAGGER"); xa.stagger = sg ? atoi(sg) : 0; } // x 512 cycles; 0 is best for the packed kernel, 1 for the scalar one
+        static const int stagger = [] { const char *sg = getenv("CRSDR_K1_STAGGER"); return sg ? atoi(sg) : 0; }();
+        xa.stagger = stagger; // x 512 cycles; 0 is best for the packed kernel, 1 for the scalar one
         xa.lag = o_lag; xa.mag = o_mag; xa.frac = o_frac;
         xa.lag_state = p->d_lag_state; xa.mag_state = p->d_mag_state; xa.frac_state = p->d_frac_state;
         HIP_TRY(hipStreamWaitEvent(KS, p->ev_ref[slot], 0));

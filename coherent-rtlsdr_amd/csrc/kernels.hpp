@@ -230,6 +230,19 @@ __device__ __forceinline__ uint4 shifted_vec(const int8_t *__restrict__ srow, in
     return v;
 }
 
+// sum of v over the 64 lanes of a wave, valid in lane 63 (all lanes must be active): four row_shr steps leave each
+// 16-lane row's sum in its last lane, row_bcast:15 / row_bcast:31 carry them up to lane 63 -- VALU only, no LDS crossbar
+__device__ __forceinline__ int wave_sum_lane63(int v)
+{
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);   // row_shr:1
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);   // row_shr:2
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);   // row_shr:4
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);   // row_shr:8
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);   // row_bcast:15 into rows 1 and 3
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);   // row_bcast:31 into rows 2 and 3
+    return v;
+}
+
 __device__ __forceinline__ void dot_word(uint32_t s, uint32_t r, int &re, int &im)
 {
     // bytes of a word: [I0 Q0 I1 Q1]
@@ -499,6 +512,14 @@ __global__ __launch_bounds__(kAlignThreads, 8) void k_align_fused(AlignArgs a, F
     // straddle; a branch around each load would make the compiler wait for one before issuing the next).
     uint4 sv[4], rv[4];
     bool edge = false;
+    if (a.refnoise) {                            // first: these do not wait for the lag
+        const uint4 *r128 = reinterpret_cast<const uint4 *>(blk);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int i = tid + q * kAlignThreads;
+            rv[q] = r128[(FULL || i < nvec) ? i : 0];
+        }
+    }
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const int i = tid + q * kAlignThreads;
@@ -507,14 +528,6 @@ __global__ __launch_bounds__(kAlignThreads, 8) void k_align_fused(AlignArgs a, F
         const u4_unaligned u = *reinterpret_cast<const u4_unaligned *>(srow + 2 * (ptrdiff_t)(inside ? m0 : 0));
         sv[q] = make_uint4(u.x, u.y, u.z, u.w);
         edge |= !inside;
-    }
-    if (a.refnoise) {
-        const uint4 *r128 = reinterpret_cast<const uint4 *>(blk);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int i = tid + q * kAlignThreads;
-            rv[q] = r128[(FULL || i < nvec) ? i : 0];
-        }
     }
     if (edge) {
 #pragma unroll
@@ -552,13 +565,10 @@ __global__ __launch_bounds__(kAlignThreads, 8) void k_align_fused(AlignArgs a, F
                 dot_word(sv[q].w, rv[q].w ^ a.xor80, re, im);
             }
         }
-        long long acc_re = re, acc_im = im;
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) {
-            acc_re += __shfl_xor(acc_re, off, 64);
-            acc_im += __shfl_xor(acc_im, off, 64);
-        }
-        if ((tid & 63) == 0) { sred[2 * (tid >> 6)] = acc_re; sred[2 * (tid >> 6) + 1] = acc_im; }
+        // B <= 16384 here: |sum| <= 8192 * 2 * 127^2 < 2^28, so the wave sums are exact in 32 bits (six DPP adds each)
+        re = wave_sum_lane63(re);
+        im = wave_sum_lane63(im);
+        if ((tid & 63) == 63) { sred[2 * (tid >> 6)] = re; sred[2 * (tid >> 6) + 1] = im; }
     }
     __syncthreads();
     // unit phasor conj(corr)/|corr| from the integer sums; 0 = "|corr| == 0, hold the previous phasor"
