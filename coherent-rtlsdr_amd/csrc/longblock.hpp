@@ -84,7 +84,7 @@ __device__ __forceinline__ void col_fft(float2 *T, const float2 *__restrict__ tw
 // grid (ntiles, rows); tile = columns [tile*C, (tile+1)*C), C = TILE / N1.  Signal rows carry samples at n < L
 // (n1 < N1/2), the ref row at n >= L (src/crtlsdr.cc:205-207,215-218).
 template <int LOG2N1, bool IS_REF>
-__global__ __launch_bounds__(THREADS) void k_long_fwd_cols(const int8_t *__restrict__ rows, int row_begin, uint32_t xor80,
+__global__ __launch_bounds__(THREADS, 2) void k_long_fwd_cols(const int8_t *__restrict__ rows, int row_begin, uint32_t xor80,
                                                            LongTw tw, float2 *__restrict__ Y)
 {
     constexpr int N1 = 1 << LOG2N1, LOG2C = LOG2TILE - LOG2N1, C = 1 << LOG2C, H = N1 / 2;
@@ -95,21 +95,45 @@ __global__ __launch_bounds__(THREADS) void k_long_fwd_cols(const int8_t *__restr
     const int row = IS_REF ? 0 : row_begin + (int)blockIdx.y;
     const uint32_t *src = reinterpret_cast<const uint32_t *>(rows + (size_t)row * B); // word = 2 samples
     // non-zero half: H tile rows of C samples; the other H rows are zero
-    for (int w = tid; w < H * C / 2; w += THREADS) {
-        const int n1 = (2 * w) >> LOG2C, c = (2 * w) & (C - 1);
-        const uint32_t u = src[((size_t)n1 * N2 + (size_t)tile * C + c) >> 1] ^ xor80;
+    constexpr int WORDS = H * C / 2 / THREADS;     // = TILE / 4 / THREADS input words per thread, all loaded before the first use
+    uint32_t u[WORDS];
+#pragma unroll
+    for (int i = 0; i < WORDS; ++i) {
+        const int w = tid + i * THREADS, n1 = (2 * w) >> LOG2C, c = (2 * w) & (C - 1);
+        u[i] = src[((size_t)n1 * N2 + (size_t)tile * C + c) >> 1];
+    }
+#pragma unroll
+    for (int i = 0; i < WORDS; ++i) {
+        const int w = tid + i * THREADS, n1 = (2 * w) >> LOG2C, c = (2 * w) & (C - 1);
+        const uint32_t x = u[i] ^ xor80;
         const int r = IS_REF ? n1 + H : n1;
-        T[(r << LOG2C) + c] = make_float2(i8_to_f32(sext8(u, 0)), i8_to_f32(sext8(u, 1)));
-        T[(r << LOG2C) + c + 1] = make_float2(i8_to_f32(sext8(u, 2)), i8_to_f32(sext8(u, 3)));
+        *reinterpret_cast<float4 *>(T + (r << LOG2C) + c) =
+            make_float4(i8_to_f32(sext8(x, 0)), i8_to_f32(sext8(x, 1)), i8_to_f32(sext8(x, 2)), i8_to_f32(sext8(x, 3)));
     }
     for (int e = tid; e < H * C; e += THREADS) T[((IS_REF ? 0 : H) << LOG2C) + e] = make_float2(0.f, 0.f);
     __syncthreads();
     col_fft<LOG2N1, -1>(T, tw.tw1, tid);
     float2 *Yr = Y + (size_t)(IS_REF ? 0 : blockIdx.y) * B;
-    for (int e = tid; e < TILE; e += THREADS) {
-        const int j = e >> LOG2C, c = e & (C - 1);
+    // a thread's 16 outputs as 8 column pairs: all 32 twiddle-table loads are issued before the first product
+    // (a rolled loop waits out a memory round trip per few elements), the stores are 16 bytes wide
+    constexpr int PAIRS = TILE / 2 / THREADS;
+    float2 wc[2 * PAIRS], wf[2 * PAIRS];
+#pragma unroll
+    for (int i = 0; i < PAIRS; ++i) {
+        const int e = 2 * (tid + i * THREADS), j = e >> LOG2C, c = e & (C - 1);
+        const uint32_t k1 = (uint32_t)rev_n1<LOG2N1>(j), n2 = (uint32_t)(tile * C + c);
+        const uint32_t m0 = (n2 * k1) & tw.bmask, m1 = ((n2 + 1u) * k1) & tw.bmask;
+        wc[2 * i] = tw.wc[m0 >> FBITS]; wf[2 * i] = tw.wf[m0 & ((1u << FBITS) - 1)];
+        wc[2 * i + 1] = tw.wc[m1 >> FBITS]; wf[2 * i + 1] = tw.wf[m1 & ((1u << FBITS) - 1)];
+    }
+#pragma unroll
+    for (int i = 0; i < PAIRS; ++i) {
+        const int e = 2 * (tid + i * THREADS), j = e >> LOG2C, c = e & (C - 1);
         const int k1 = rev_n1<LOG2N1>(j), n2 = tile * C + c;
-        Yr[(size_t)k1 * N2 + n2] = cmul(T[e], tw_big(tw, (uint32_t)n2 * (uint32_t)k1));
+        const float4 t = *reinterpret_cast<const float4 *>(T + e);
+        const float2 y0 = cmul(make_float2(t.x, t.y), cmul(wc[2 * i], wf[2 * i]));
+        const float2 y1 = cmul(make_float2(t.z, t.w), cmul(wc[2 * i + 1], wf[2 * i + 1]));
+        *reinterpret_cast<float4 *>(Yr + (size_t)k1 * N2 + n2) = make_float4(y0.x, y0.y, y1.x, y1.y);
     }
 }
 
@@ -122,7 +146,7 @@ struct LongPartial {
 };
 
 template <int LOG2N1>
-__global__ __launch_bounds__(THREADS) void k_long_inv_cols(const float2 *__restrict__ Z, LongTw tw, LongPartial *__restrict__ part)
+__global__ __launch_bounds__(THREADS, 2) void k_long_inv_cols(const float2 *__restrict__ Z, LongTw tw, LongPartial *__restrict__ part)
 {
     constexpr int N1 = 1 << LOG2N1, LOG2C = LOG2TILE - LOG2N1, C = 1 << LOG2C;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -131,9 +155,32 @@ __global__ __launch_bounds__(THREADS) void k_long_inv_cols(const float2 *__restr
     const int tid = threadIdx.x, tile = blockIdx.x;
     const size_t B = (size_t)N1 * N2;
     const float2 *Zr = Z + (size_t)blockIdx.y * B;
-    for (int e = tid; e < TILE; e += THREADS) {
-        const int k1 = e >> LOG2C, c = e & (C - 1), n2 = tile * C + c;
-        T[e] = cmulc(Zr[(size_t)k1 * N2 + n2], tw_big(tw, (uint32_t)n2 * (uint32_t)k1));
+    {
+        // a thread's 16 inputs as 8 column pairs: every load (8 x 16 bytes of Z, 32 twiddle-table entries) is in
+        // flight before the first product -- in a rolled loop each few elements cost a memory round trip
+        constexpr int PAIRS = TILE / 2 / THREADS;
+        float4 z[PAIRS];
+        float2 wc[2 * PAIRS], wf[2 * PAIRS];
+#pragma unroll
+        for (int i = 0; i < PAIRS; ++i) {
+            const int e = 2 * (tid + i * THREADS), k1 = e >> LOG2C, c = e & (C - 1), n2 = tile * C + c;
+            z[i] = *reinterpret_cast<const float4 *>(Zr + (size_t)k1 * N2 + n2);
+        }
+#pragma unroll
+        for (int i = 0; i < PAIRS; ++i) {
+            const int e = 2 * (tid + i * THREADS);
+            const uint32_t k1 = (uint32_t)(e >> LOG2C), n2 = (uint32_t)(tile * C + (e & (C - 1)));
+            const uint32_t m0 = (n2 * k1) & tw.bmask, m1 = ((n2 + 1u) * k1) & tw.bmask;
+            wc[2 * i] = tw.wc[m0 >> FBITS]; wf[2 * i] = tw.wf[m0 & ((1u << FBITS) - 1)];
+            wc[2 * i + 1] = tw.wc[m1 >> FBITS]; wf[2 * i + 1] = tw.wf[m1 & ((1u << FBITS) - 1)];
+        }
+#pragma unroll
+        for (int i = 0; i < PAIRS; ++i) {
+            const int e = 2 * (tid + i * THREADS);
+            const float2 y0 = cmulc(make_float2(z[i].x, z[i].y), cmul(wc[2 * i], wf[2 * i]));
+            const float2 y1 = cmulc(make_float2(z[i].z, z[i].w), cmul(wc[2 * i + 1], wf[2 * i + 1]));
+            *reinterpret_cast<float4 *>(T + e) = make_float4(y0.x, y0.y, y1.x, y1.y);
+        }
     }
     __syncthreads();
     col_fft<LOG2N1, +1>(T, tw.tw1, tid);
