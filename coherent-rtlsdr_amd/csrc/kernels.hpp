@@ -243,6 +243,31 @@ __device__ __forceinline__ int wave_sum_lane63(int v)
     return v;
 }
 
+// U vectors i0, i0 + stride, ... (those < i_end) with all loads issued back to back: a vector that straddles or lies
+// outside [0,L) loads the row start instead and is patched afterwards (a branch around every load would make the
+// compiler wait for one before issuing the next)
+template <int U>
+__device__ __forceinline__ void shifted_vecs(uint4 (&sv)[U], const int8_t *__restrict__ srow, int i0, int stride, int i_end, int d, int L,
+                                             uint32_t xor80)
+{
+    bool edge = false;
+#pragma unroll
+    for (int q = 0; q < U; ++q) {
+        const int i = i0 + q * stride, m0 = 8 * i + d;
+        const bool live = i < i_end, inside = live && m0 >= 0 && m0 + 8 <= L;
+        const u4_unaligned u = *reinterpret_cast<const u4_unaligned *>(srow + 2 * (ptrdiff_t)(inside ? m0 : 0));
+        sv[q] = make_uint4(u.x ^ xor80, u.y ^ xor80, u.z ^ xor80, u.w ^ xor80);
+        edge |= live && !inside;
+    }
+    if (edge) {
+#pragma unroll
+        for (int q = 0; q < U; ++q) {
+            const int i = i0 + q * stride, m0 = 8 * i + d;
+            if (i < i_end && !(m0 >= 0 && m0 + 8 <= L)) sv[q] = shifted_vec(srow, i, d, L, xor80);
+        }
+    }
+}
+
 __device__ __forceinline__ void dot_word(uint32_t s, uint32_t r, int &re, int &im)
 {
     // bytes of a word: [I0 Q0 I1 Q1]
@@ -271,14 +296,23 @@ __global__ __launch_bounds__(kAlignThreads) void k_phase_dot(AlignArgs a)
     if constexpr (VEC) {
         const int8_t *srow = blk + (size_t)row * B;
         const uint4 *r128 = reinterpret_cast<const uint4 *>(blk);
-#pragma unroll 4
-        for (int i = v_lo + tid; i < v_hi; i += kAlignThreads) {
-            const uint4 sv = shifted_vec(srow, i, d, L, a.xor80);
-            const uint4 rv = r128[i];
-            dot_word(sv.x, rv.x ^ a.xor80, re, im);
-            dot_word(sv.y, rv.y ^ a.xor80, re, im);
-            dot_word(sv.z, rv.z ^ a.xor80, re, im);
-            dot_word(sv.w, rv.w ^ a.xor80, re, im);
+        for (int i0 = v_lo + tid; i0 < v_hi; i0 += 4 * kAlignThreads) {
+            uint4 sv[4], rv[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int i = i0 + q * kAlignThreads;
+                rv[q] = r128[i < v_hi ? i : i0];
+            }
+            shifted_vecs<4>(sv, srow, i0, kAlignThreads, v_hi, d, L, a.xor80);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                if (i0 + q * kAlignThreads < v_hi) {
+                    dot_word(sv[q].x, rv[q].x ^ a.xor80, re, im);
+                    dot_word(sv[q].y, rv[q].y ^ a.xor80, re, im);
+                    dot_word(sv[q].z, rv[q].z ^ a.xor80, re, im);
+                    dot_word(sv[q].w, rv[q].w ^ a.xor80, re, im);
+                }
+            }
         }
     } else {
         for (int i = 4 * v_lo + tid; i < 4 * v_hi; i += kAlignThreads) {
@@ -423,10 +457,14 @@ __global__ __launch_bounds__(kAlignThreads) void k_align_quant(AlignArgs a)
     if constexpr (VEC) {
         const int8_t *srow = blk + (size_t)row * B;
         uint4 *o128 = reinterpret_cast<uint4 *>(orow);
-#pragma unroll 4
-        for (int i = v_lo + tid; i < v_hi; i += kAlignThreads) {
-            const uint4 sv = shifted_vec(srow, i, d, L, a.xor80);
-            o128[i] = make_uint4(rotq_word(sv.x, p), rotq_word(sv.y, p), rotq_word(sv.z, p), rotq_word(sv.w, p));
+        for (int i0 = v_lo + tid; i0 < v_hi; i0 += 4 * kAlignThreads) {
+            uint4 sv[4];
+            shifted_vecs<4>(sv, srow, i0, kAlignThreads, v_hi, d, L, a.xor80);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int i = i0 + q * kAlignThreads;
+                if (i < v_hi) o128[i] = make_uint4(rotq_word(sv[q].x, p), rotq_word(sv[q].y, p), rotq_word(sv[q].z, p), rotq_word(sv[q].w, p));
+            }
         }
     } else {
         uint32_t *o32 = reinterpret_cast<uint32_t *>(orow);
