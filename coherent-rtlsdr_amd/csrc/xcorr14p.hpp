@@ -230,12 +230,18 @@ __device__ __forceinline__ void xcorr_row14(const XcorrArgs &a, unsigned char *s
     for (int i = 1; i < 31; i += 2) tm = fmaxf(tm, fmaxf(m[i], m[i + 1]));
     tm = fmaxf(tm, m[31]);
     CRSDR_STAMP(7);
+    // wave maximum in lane 63: four row_shr steps (lane 15 of each 16-lane row holds the row's maximum), then
+    // row_bcast:15 / row_bcast:31 -- six DPP v_max instead of six trips through the LDS crossbar
     float wm = tm;
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) wm = fmaxf(wm, __shfl_xor(wm, off, 64));
+    wm = fmaxf(wm, __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(wm), __float_as_int(wm), 0x111, 0xf, 0xf, false)));
+    wm = fmaxf(wm, __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(wm), __float_as_int(wm), 0x112, 0xf, 0xf, false)));
+    wm = fmaxf(wm, __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(wm), __float_as_int(wm), 0x114, 0xf, 0xf, false)));
+    wm = fmaxf(wm, __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(wm), __float_as_int(wm), 0x118, 0xf, 0xf, false)));
+    wm = fmaxf(wm, __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(wm), __float_as_int(wm), 0x142, 0xa, 0xf, false)));
+    wm = fmaxf(wm, __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(wm), __float_as_int(wm), 0x143, 0xc, 0xf, false)));
     int *redi = reinterpret_cast<int *>(red);
     if (tid == 0) redi[16] = 0x7fffffff;
-    if ((tid & 63) == 0) red[tid >> 6] = wm;
+    if ((tid & 63) == 63) red[tid >> 6] = wm;
     __syncthreads();
     float gm = red[0];
 #pragma unroll
