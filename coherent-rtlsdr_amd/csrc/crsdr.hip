@@ -590,7 +590,9 @@ struct crsdr_plan {
     int32_t *d_lag = nullptr, *d_lag_state = nullptr;         // [T][nrows], [nrows]
     float *d_mag = nullptr, *d_frac = nullptr, *d_mag_state = nullptr, *d_frac_state = nullptr;
     float2 *d_phasor = nullptr, *d_phase_state[2] = {nullptr, nullptr}; // [T][nrows], 2 x [nrows]
-    long long *d_corr = nullptr;       // [T][nrows][2]
+    long long *d_corr = nullptr;       // [T][nrows][2]: integer sums (three-kernel path) or the fused kernel's two hand-over slots
+    int chain_slot = 0;                // fused path: slot [chain_slot] of every entry carries this batch's unit phasors,
+    int chain_armed[2] = {0, 0};       // the kernel re-arms the other one; leading blocks of each slot known to be all-ones
     unsigned int *d_sync = nullptr;    // fused K2: [0] ticket counter, [1] status
     bool fused_k2 = true, fused_used = false;
     int phase_cur = 0;
@@ -639,7 +641,8 @@ static int plan_init_state(crsdr_plan *p)
     HIP_TRY(hipMemset(p->d_lag_state, 0, sizeof(int32_t) * n));
     HIP_TRY(hipMemset(p->d_mag_state, 0, sizeof(float) * n));
     HIP_TRY(hipMemset(p->d_frac_state, 0, sizeof(float) * n));
-    HIP_TRY(hipMemset(p->d_corr, 0, sizeof(long long) * 2 * n * T));
+    HIP_TRY(hipMemset(p->d_corr, 0xFF, sizeof(long long) * 2 * n * T));
+    p->chain_armed[0] = p->chain_armed[1] = (int)T;
     p->phase_cur = 0;
     p->last_nblocks = 0;
     return CRSDR_OK;
@@ -1029,10 +1032,23 @@ extern "C" int crsdr_plan_submit_batch(crsdr_plan *p, const void *rows, int mem_
     if (fused) {
         // fused phase path: every row is read once (k_align_fused); timed under CRSDR_KERNEL_ALIGN_QUANT
         static const int spin_limit = [] { const char *e = getenv("CRSDR_K2_SPIN"); return e ? atoi(e) : kFusedSpinLimit; }();
-        FusedSync fs{p->d_sync, p->d_sync + 1, reinterpret_cast<unsigned long long *>(p->d_corr), p->row_count, spin_limit};
+        // hand-over words: two slots per (row, block).  A batch publishes into one and its workgroups re-arm the other
+        // (all-ones) for the next batch, so the steady state needs no memset between launches; the host only tracks how
+        // many leading blocks of each slot are armed and falls back to a memset when a batch needs more than that
+        const int cs = p->chain_slot;
+        unsigned long long *chain = reinterpret_cast<unsigned long long *>(p->d_corr);
+        FusedSync fs{p->d_sync, p->d_sync + 1, chain + cs, aa.refnoise ? chain + (cs ^ 1) : nullptr, p->row_count, spin_limit};
         hipEvent_t *pe = prof_pair(p, CRSDR_KERNEL_ALIGN_QUANT);
         if (pe) HIP_TRY(hipEventRecord(pe[0], S));
-        if (aa.refnoise && nblocks > 1) HIP_TRY(hipMemsetAsync(p->d_corr, 0xFF, sizeof(long long) * 2 * n * T, S)); // re-arm the chain
+        if (aa.refnoise) {
+            if (nblocks > 1 && p->chain_armed[cs] < nblocks) {
+                HIP_TRY(hipMemsetAsync(p->d_corr, 0xFF, sizeof(long long) * 2 * n * T, S));
+                p->chain_armed[0] = p->chain_armed[1] = (int)T;
+            }
+            p->chain_armed[cs] = 0;                                             // published into
+            p->chain_armed[cs ^ 1] = std::max(p->chain_armed[cs ^ 1], nblocks); // re-armed by this launch
+            p->chain_slot = cs ^ 1;
+        }
         if (p->B == 16384) hipLaunchKernelGGL(k_align_fused<true>, dim3((unsigned)((1 + p->row_count) * nblocks)), dim3(kAlignThreads), 0, S, aa, fs);
         else hipLaunchKernelGGL(k_align_fused<false>, dim3((unsigned)((1 + p->row_count) * nblocks)), dim3(kAlignThreads), 0, S, aa, fs);
         HIP_TRY(hipGetLastError());
@@ -1050,6 +1066,7 @@ extern "C" int crsdr_plan_submit_batch(crsdr_plan *p, const void *rows, int mem_
     if (aa.refnoise) {
         hipEvent_t *pe = prof_pair(p, CRSDR_KERNEL_PHASE_DOT);
         if (pe) HIP_TRY(hipEventRecord(pe[0], S));
+        p->chain_armed[0] = p->chain_armed[1] = 0;   // this path keeps its integer sums in d_corr
         if (chunks > 1) HIP_TRY(hipMemsetAsync(p->d_corr, 0, sizeof(long long) * 2 * n * T, S)); // atomically accumulated
         if (vec16) hipLaunchKernelGGL(k_phase_dot<true>, dim3(p->row_count, nblocks, chunks), dim3(kAlignThreads), 0, S, aa);
         else hipLaunchKernelGGL(k_phase_dot<false>, dim3(p->row_count, nblocks, chunks), dim3(kAlignThreads), 0, S, aa);

@@ -500,7 +500,8 @@ __global__ __launch_bounds__(kAlignThreads) void k_align_quant(AlignArgs a)
 struct FusedSync {
     unsigned int *ticket;              // unused (kept for a ticketed variant)
     unsigned int *status;              // [0] number of look-back waits that ran out and were computed locally
-    unsigned long long *chain;         // [T][nrows][2]: [0] = phasor bits or all-ones
+    unsigned long long *chain;         // [T][nrows] at stride 2: this batch's unit phasor bits, all-ones = not yet
+    unsigned long long *rearm;         // the other slot of the same entries: reset to all-ones for the next batch (or null)
     int row_count;
     int spin_limit;                    // polls before the local fallback (kFusedSpinLimit); < 0: treat every earlier block as missing (tests)
 };
@@ -628,6 +629,7 @@ __global__ __launch_bounds__(kAlignThreads, 8) void k_align_fused(AlignArgs a, F
                 for (int w = 0; w < kAlignThreads / 64; ++w) { sr += sred[2 * w]; si += sred[2 * w + 1]; }
                 mine = unit_bits(sr, si);
                 __hip_atomic_store(fs.chain + 2 * o, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (fs.rearm) fs.rearm[2 * o] = kChainEmpty;    // nobody reads this slot before the next launch
             }
             // lane u < t holds the unit phasor of block u (published right after that block's dot product, long
             // before its own rotation) from the prefetch above, or polls for it now; lane t takes this block's
