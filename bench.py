@@ -245,7 +245,7 @@ def main():
             "metric": f"aligned IQ blocks/s ({nsig} ch x {L})", "value": blocks_per_s, "unit": "blocks/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{'cfg5' if args.cfg5 else 'cfg4'}: 1 ref + {nsig} signal rows x {L} int8 IQ samples per block, track cadence "
+            "config": {"workload": f"{'cfg5' if args.cfg5 else {21: 'cfg2', 256: 'cfg3', 1024: 'cfg4'}.get(nsig, 'custom') if L == 8192 else 'custom'}: 1 ref + {nsig} signal rows x {L} int8 IQ samples per block, track cadence "
                                    f"(FFT xcorr every block), {args.mode} mode, inputs resident in HBM, "
                                    f"{nbuf} rotating input blocks, {T} blocks per submit",
                        "rows": nrows, "L": L, "fft_len": B, "mode": args.mode, "batch": T,
