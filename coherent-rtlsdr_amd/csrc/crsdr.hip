@@ -216,6 +216,21 @@ static hipError_t launch_xcorr_lag14(hipStream_t s, const XcorrArgs &a, int row_
         hipLaunchKernelGGL(kp, dim3(row_count, a.nblocks), dim3(x14::THREADS), x14::LDS_BYTES, s, a, twA, twB);
         return hipGetLastError();
     }
+    if (variant == 'q') {   // two rows per CU in opposite phases (xcorr14q.hpp), one persistent workgroup per CU
+        auto kq = x14p::k_xcorr_lag14q;
+        hipError_t eq = hipFuncSetAttribute((const void *)kq, hipFuncAttributeMaxDynamicSharedMemorySize, x14p::LDSQ_BYTES);
+        if (eq != hipSuccess) return eq;
+        static const int cus = [] {
+            int dev = 0, n = 0;
+            if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 1) n = 256;
+            const char *e = getenv("CRSDR_K1_QGRID");
+            return e ? atoi(e) : n;
+        }();
+        const int items = row_count * a.nblocks;
+        hipLaunchKernelGGL(kq, dim3((unsigned)std::max(1, std::min(cus, (items + 1) / 2))), dim3(2 * x14p::QG), x14p::LDSQ_BYTES, s, a, twA, twB, row_count,
+                           (int *)nullptr);
+        return hipGetLastError();
+    }
     if (half) {
         auto kh = x14h::k_xcorr_lag14h;
         hipError_t eh = hipFuncSetAttribute((const void *)kh, hipFuncAttributeMaxDynamicSharedMemorySize, x14h::LDS_BYTES_H);

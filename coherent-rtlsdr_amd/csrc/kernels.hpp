@@ -25,6 +25,7 @@
 #include "xcorr14.hpp"
 #include "xcorr14h.hpp"
 #include "xcorr14p.hpp"
+#include "xcorr14q.hpp"
 #include "longblock.hpp"
 #include "covariance.hpp"
 #include "music.hpp"

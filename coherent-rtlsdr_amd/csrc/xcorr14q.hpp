@@ -1,0 +1,316 @@
+// xcorr14q.hpp -- K1 with TWO rows per CU in opposite phases (experiment, CRSDR_K1_VARIANT=q).
+//
+// tools/lds_valu_overlap.hip: on one SIMD the LDS stores of one wave overlap the packed VALU stream of the other,
+// but K1's two waves per SIMD run the same row and hit their store bursts together, so a row costs VALU time PLUS
+// store time.  Here one persistent 512-thread workgroup runs two rows at once: waves 0-3 (one per SIMD) are group 0,
+// waves 4-7 group 1, every thread does the work of two threads of xcorr14p.hpp one after the other (virtual threads
+// tid and tid + 256: same passes, same LDS image, same arithmetic -> identical bits).  A row needs the one 132 KiB
+// image only from its P0 stores to its P0' loads; outside that window (P0' arithmetic, epilogue, the next row's loads
+// and first butterflies) a group touches no LDS, and that is when the other group owns the image and does its
+// store-heavy middle section.  Hand-over: one owner word in LDS (compare-and-swap by every wave, tagged with the
+// row's sequence number), released by the last wave of the owner group that has its P0' values in registers.
+// Barriers inside a group (4 waves) are LDS counters: s_barrier would join both groups.
+// Every wait is bounded; running out sets an error word (rows then hold garbage, the kernel still terminates).
+#pragma once
+#include "xcorr14p.hpp"
+
+namespace crsdr {
+namespace x14p {
+
+constexpr int QG = 256;                                       // threads per row group
+constexpr int LDSQ_BYTES = LDS_ELEMS * 8 + 2 * 512 + 64;      // image + a reduction scratch per group + sync words
+constexpr int kQSpinLimit = 1 << 18;
+
+struct QSync {
+    int owner;      // 0 = image free, else 2 * seq + group + 1
+    int relcnt;     // waves of the owner group that hold their P0' values
+    int bar[2];     // arrivals at each group's barrier (monotonic)
+    int err;        // a bounded wait ran out
+};
+
+#ifdef CRSDR_QDEBUG
+#define QDBG_T0 const unsigned long long t0__ = __builtin_readcyclecounter();
+#define QDBG_ADD(slot) if (dbg__ && blockIdx.x == 0 && (threadIdx.x & 63) == 0) atomicAdd(dbg__ + (slot), (unsigned long long)(__builtin_readcyclecounter() - t0__));
+#else
+#define QDBG_T0
+#define QDBG_ADD(slot)
+#endif
+__device__ unsigned long long *dbg__ = nullptr;
+__device__ __forceinline__ void q_barrier(QSync *s, int g, int &gen)
+{
+    QDBG_T0
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_add(&s->bar[g], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    gen += QG / 64;
+    int spins = 0;
+    while (__hip_atomic_load(&s->bar[g], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < gen) {
+        if (++spins > kQSpinLimit || __hip_atomic_load(&s->err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) {
+            __hip_atomic_store(&s->err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            break;
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    QDBG_ADD(1)
+}
+
+__device__ __forceinline__ void q_acquire(QSync *s, int tag)
+{
+    QDBG_T0
+    int spins = 0;
+    for (;;) {
+        int old = tag;
+        if ((threadIdx.x & 63) == 0) {
+            int expected = 0;
+            __hip_atomic_compare_exchange_strong(&s->owner, &expected, tag, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            old = expected;                    // 0 if this wave took it, else the current owner
+        }
+        old = __builtin_amdgcn_readfirstlane(old);
+        if (old == 0 || old == tag) break;
+        __builtin_amdgcn_s_sleep(2);
+        if (++spins > kQSpinLimit || __hip_atomic_load(&s->err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) {
+            __hip_atomic_store(&s->err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            break;
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    QDBG_ADD(2)
+}
+
+__device__ __forceinline__ void q_release(QSync *s)
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");      // this wave's image loads have returned
+    if ((threadIdx.x & 63) == 0) {
+        const int n = __hip_atomic_fetch_add(&s->relcnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (n == QG / 64 - 1) {
+            __hip_atomic_store(&s->relcnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_store(&s->owner, 0, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+    }
+}
+
+// P0 of one virtual thread without the stores (pass0_forward<false> of xcorr14p.hpp)
+__device__ __forceinline__ void q_p0_compute(c2 *v, const int8_t *__restrict__ row, const c2 *__restrict__ twA, uint32_t xor80, int vt)
+{
+    const uint16_t *src = reinterpret_cast<const uint16_t *>(row);
+    const uint32_t x16 = xor80 & 0xFFFFu;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const uint32_t u = (uint32_t)src[i * 512 + vt] ^ x16;
+        v[i] = mk((float)sext8(u, 0), (float)sext8(u, 1));
+    }
+    dft32_stage1_pruned<0, false>(v);
+    dft16p<-1>(v);
+    dft16p<-1>(v + 16);
+    c2 w[32];
+    tw_load(w, twA, TWA_STRIDE, vt);
+    tw_apply<-1, true, 1>(v, w);
+}
+__device__ __forceinline__ void q_p0_store(c2 *A, const c2 *v, int vt)
+{
+    const int base = p0_base(vt);
+#pragma unroll
+    for (int k = 0; k < 32; ++k) A[base + k * 528] = v[xpos(k)];
+}
+// P0' of one virtual thread: loads, then (separately) the arithmetic down to |.|^2
+__device__ __forceinline__ void q_p0i_load(c2 *v, const c2 *A, int vt)
+{
+    const int base = p0_base(vt);
+#pragma unroll
+    for (int k = 0; k < 32; ++k) v[k] = A[base + k * 528];
+}
+__device__ __forceinline__ void q_p0i_compute(float *m, c2 *v, const c2 *__restrict__ twA, int vt)
+{
+    c2 w[32];
+    tw_load(w, twA, TWA_STRIDE, vt);
+    tw_apply<+1, false, 1>(v, w);
+    dft32<+1>(v);
+#pragma unroll
+    for (int i = 0; i < 32; ++i) {
+        const c2 x = v[xpos(i)];
+        m[i] = fmaf(x.x, x.x, x.y * x.y);
+    }
+}
+// junction of one virtual thread, one half (the J loop of xcorr_row14); the reference-spectrum values are loaded a half ahead
+__device__ __forceinline__ void q_refspec_load(float4 *r, const float4 *__restrict__ refspec4, int vt, int h)
+{
+    const int g = ((vt >> 6) << 7) + 64 * h + (vt & 63);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) r[j] = refspec4[j * 1024 + g];
+}
+__device__ __forceinline__ void q_junction_half(float4 *A4, const float4 *r, int vt, int h)
+{
+    const int g = ((vt >> 6) << 7) + 64 * h + (vt & 63), base = j_base(g), key = g & 7;
+    c2 u[16];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        float4 q = A4[base + (j ^ key)];
+        u[2 * j] = mk(q.x, q.y);
+        u[2 * j + 1] = mk(q.z, q.w);
+    }
+    dft16p<-1>(u);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        u[2 * j] = cmul(u[2 * j], mk(r[j].x, r[j].y));
+        u[2 * j + 1] = cmul(u[2 * j + 1], mk(r[j].z, r[j].w));
+    }
+    dft16p<+1>(u);
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+        A4[base + (j ^ key)] = make_float4(u[2 * j].x, u[2 * j].y, u[2 * j + 1].x, u[2 * j + 1].y);
+}
+
+__device__ __forceinline__ float q_wave_max63(float wm)
+{
+    wm = fmaxf(wm, __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(wm), __float_as_int(wm), 0x111, 0xf, 0xf, false)));
+    wm = fmaxf(wm, __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(wm), __float_as_int(wm), 0x112, 0xf, 0xf, false)));
+    wm = fmaxf(wm, __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(wm), __float_as_int(wm), 0x114, 0xf, 0xf, false)));
+    wm = fmaxf(wm, __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(wm), __float_as_int(wm), 0x118, 0xf, 0xf, false)));
+    wm = fmaxf(wm, __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(wm), __float_as_int(wm), 0x142, 0xa, 0xf, false)));
+    wm = fmaxf(wm, __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(wm), __float_as_int(wm), 0x143, 0xc, 0xf, false)));
+    return wm;      // valid in lane 63
+}
+
+// grid: one workgroup per CU; items = owned rows x blocks, item (2k + g) * gridDim.x + blockIdx.x goes to group g
+__global__ __launch_bounds__(2 * QG, 1) void k_xcorr_lag14q(XcorrArgs a, const float2 *__restrict__ twA_, const float2 *__restrict__ twB_,
+                                                           int row_count, int *__restrict__ errflag)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const c2 *twA = reinterpret_cast<const c2 *>(twA_), *twB = reinterpret_cast<const c2 *>(twB_);
+    c2 *A = reinterpret_cast<c2 *>(smem);
+    float4 *A4 = reinterpret_cast<float4 *>(smem);
+    const int g = threadIdx.x >> 8, tid = threadIdx.x & (QG - 1);
+    float *red = reinterpret_cast<float *>(smem + (size_t)LDS_ELEMS * 8 + 512 * g);
+    int *redi = reinterpret_cast<int *>(red);
+    QSync *sy = reinterpret_cast<QSync *>(smem + (size_t)LDS_ELEMS * 8 + 1024);
+    if (threadIdx.x == 0) { sy->owner = 0; sy->relcnt = 0; sy->bar[0] = 0; sy->bar[1] = 0; sy->err = 0; }
+    __syncthreads();
+    int gen = 0;
+#ifdef CRSDR_QDEBUG
+    const unsigned long long tk0__ = __builtin_readcyclecounter();
+#endif
+    const int nitems = row_count * a.nblocks;
+    const int vt0 = tid, vt1 = tid + QG;
+    for (int k = 0;; ++k) {
+        const int item = (2 * k + g) * (int)gridDim.x + (int)blockIdx.x;
+        if (item >= nitems) break;
+        const int t = item / row_count, row = a.row_begin + item % row_count;
+        if (xcorr_skip(a, row, t, tid)) continue;
+        const int8_t *src = a.rows + (size_t)t * a.block_stride + (size_t)row * N;
+        const float4 *__restrict__ refspec4 = reinterpret_cast<const float4 *>(a.refspec) + (size_t)t * (N / 2);
+        {
+            c2 v[32], v2[32];
+            q_p0_compute(v, src, twA, a.xor80, vt0);      // no LDS yet: both halves run beside the other group's middle section
+            q_p0_compute(v2, src, twA, a.xor80, vt1);
+            q_acquire(sy, 2 * k + g + 1);
+            __builtin_amdgcn_s_setprio(3);                // the owner's window is what the pair's period is made of
+            q_p0_store(A, v, vt0);
+            q_p0_store(A, v2, vt1);
+        }
+        c2 wB[32];
+        tw_load(wB, twB, TWB_STRIDE, tid & 15);
+        float4 ra[8], rb[8];
+        q_refspec_load(ra, refspec4, vt0, 0);
+        q_barrier(sy, g, gen);
+        pass1_forward(A, wB, vt0);
+        pass1_forward(A, wB, vt1);
+        wave_lds_sync();
+        q_refspec_load(rb, refspec4, vt0, 1);
+        q_junction_half(A4, ra, vt0, 0);
+        q_refspec_load(ra, refspec4, vt1, 0);
+        q_junction_half(A4, rb, vt0, 1);
+        q_refspec_load(rb, refspec4, vt1, 1);
+        q_junction_half(A4, ra, vt1, 0);
+        q_junction_half(A4, rb, vt1, 1);
+        wave_lds_sync();
+        pass1_inverse(A, wB, vt0);
+        pass1_inverse(A, wB, vt1);
+        q_barrier(sy, g, gen);
+        float m0[32], m1[32];
+        {
+            c2 v[32], v2[32];
+            q_p0i_load(v, A, vt0);
+            q_p0i_load(v2, A, vt1);
+            q_release(sy);                               // from here on this row is in registers
+            __builtin_amdgcn_s_setprio(0);
+            q_p0i_compute(m0, v, twA, vt0);
+            q_p0i_compute(m1, v2, twA, vt1);
+        }
+        // maximum value, then its first index (natural index of output i of virtual thread vt: i * 512 + vt)
+        float tm = fmaxf(m0[0], m1[0]);
+#pragma unroll
+        for (int i = 1; i < 32; ++i) tm = fmaxf(tm, fmaxf(m0[i], m1[i]));
+        const float wm = q_wave_max63(tm);
+        if (tid == 0) redi[16] = 0x7fffffff;
+        if ((tid & 63) == 63) red[tid >> 6] = wm;
+        q_barrier(sy, g, gen);
+        float gm = red[0];
+#pragma unroll
+        for (int wv = 1; wv < QG / 64; ++wv) gm = fmaxf(gm, red[wv]);
+        if (tm == gm) {
+            int bi = 0x7fffffff;
+#pragma unroll
+            for (int i = 31; i >= 0; --i) {
+                bi = (m1[i] == gm) ? i * 512 + vt1 : bi;
+                bi = (m0[i] == gm) ? i * 512 + vt0 : bi;      // vt0 < vt1: the lower index wins at the same i
+            }
+            atomicMin(&redi[16], bi);
+        }
+        q_barrier(sy, g, gen);
+        int gi = redi[16];
+        if ((unsigned)gi >= (unsigned)N) gi = 0;
+        const int pc = gi & 511, pi_ = gi >> 9;
+        const bool in_wave = ((pc & 63) != 0) && ((pc & 63) != 63);       // group-uniform
+        if (in_wave) {
+            if ((tid >> 6) == ((pc & (QG - 1)) >> 6)) {
+                float mine = 0.f;
+#pragma unroll
+                for (int i = 0; i < 32; ++i) mine = (i == pi_) ? ((pc >> 8) ? m1[i] : m0[i]) : mine;
+                const float ym = __shfl_up(mine, 1, 64), yp = __shfl_down(mine, 1, 64);
+                if (tid == (pc & (QG - 1))) {
+                    float D = 0.0f;
+                    const float den = (ym - 2.0f * gm) + yp;
+                    if (den != 0.0f) D = (0.5f * (ym - yp)) / den;
+                    xcorr_publish(a, row, t, gi - L, sqrtf(gm / (float)L) * kInvScale2, D);
+                }
+            }
+        } else {
+            const int nl = gi - 1, nr = gi + 1;
+            if (gi > 0 && ((nl & 511) & (QG - 1)) == tid) {
+                float ml = 0.f;
+#pragma unroll
+                for (int i = 0; i < 32; ++i) ml = (i == (nl >> 9)) ? (((nl & 511) >> 8) ? m1[i] : m0[i]) : ml;
+                red[32] = ml;
+            }
+            if (gi < N - 1 && ((nr & 511) & (QG - 1)) == tid) {
+                float mr = 0.f;
+#pragma unroll
+                for (int i = 0; i < 32; ++i) mr = (i == (nr >> 9)) ? (((nr & 511) >> 8) ? m1[i] : m0[i]) : mr;
+                red[33] = mr;
+            }
+            q_barrier(sy, g, gen);
+            if (tid == 0) {
+                float D = 0.0f;
+                if (gi > 0 && gi < N - 1) {
+                    const float ym = red[32], yp = red[33];
+                    const float den = (ym - 2.0f * gm) + yp;
+                    if (den != 0.0f) D = (0.5f * (ym - yp)) / den;
+                }
+                xcorr_publish(a, row, t, gi - L, sqrtf(gm / (float)L) * kInvScale2, D);
+            }
+        }
+    }
+#ifdef CRSDR_QDEBUG
+    if (dbg__ && blockIdx.x == 0 && (threadIdx.x & 63) == 0) atomicAdd(dbg__ + 0, (unsigned long long)(__builtin_readcyclecounter() - tk0__));
+#endif
+    if (threadIdx.x == 0 && errflag) {
+        // both groups may still be running: the flag is only ever set, so reading it here can miss a late error of the
+        // other group -- thread 256 reports as well
+        if (__hip_atomic_load(&sy->err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) atomicAdd(errflag, 1);
+    }
+    if (threadIdx.x == QG && errflag) {
+        if (__hip_atomic_load(&sy->err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) atomicAdd(errflag, 1);
+    }
+}
+
+} // namespace x14p
+} // namespace crsdr

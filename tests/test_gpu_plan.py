@@ -507,7 +507,7 @@ def test_k1_variants_agree(tmp_path):
                  frac=np.stack([o["frac"] for o in outs]), packet=np.stack([o["packet"] for o in outs]), d=params.d)
     ''') % root
     res = {}
-    for variant in ("scalar", "half", "packed"):
+    for variant in ("scalar", "half", "packed", "q"):
         out = tmp_path / f"{variant}.npz"
         env = dict(os.environ, CRSDR_K1_VARIANT=variant)
         r = subprocess.run([sys.executable, "-c", code, str(out)], env=env, capture_output=True, text=True, timeout=300)
@@ -516,6 +516,8 @@ def test_k1_variants_agree(tmp_path):
     # the packed kernel (default) rounds every operation like the scalar one: identical bits
     for key in ("lag", "mag", "frac", "packet"):
         assert np.array_equal(res["packed"][key].view(np.uint8), res["scalar"][key].view(np.uint8)), key
+        # q: the packed passes run by one persistent workgroup per CU, two rows in opposite phases (xcorr14q.hpp)
+        assert np.array_equal(res["packed"][key].view(np.uint8), res["q"][key].view(np.uint8)), ("q", key)
     f, h = res["scalar"], res["half"]
     assert np.array_equal(h["lag"], f["lag"]) and np.array_equal(h["lag"][0, 1:], f["d"])
     assert np.allclose(h["mag"], f["mag"], rtol=1e-5)
