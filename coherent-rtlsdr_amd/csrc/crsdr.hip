@@ -183,7 +183,8 @@ static hipError_t launch_xcorr_lag(hipStream_t s, const XcorrArgs &a, int row_co
 // on scalar fp32 ops (bit-identical results); "half" = xcorr14h.hpp for K1 only, two rows per CU (experiment, scalar K0)
 static char k1_variant()
 {
-    static const char v = [] { const char *e = getenv("CRSDR_K1_VARIANT"); return e ? e[0] : 'p'; }();
+    // unset / "auto": the two-row kernel (q) for launches with enough rows per CU, the packed one (p) otherwise
+    static const char v = [] { const char *e = getenv("CRSDR_K1_VARIANT"); return e ? e[0] : 'a'; }();
     return v == 'k' ? 'p' : v;
 }
 
@@ -205,9 +206,19 @@ static hipError_t launch_ref_spectrum14(hipStream_t s, int nblocks, const int8_t
     return hipGetLastError();
 }
 
-static hipError_t launch_xcorr_lag14(hipStream_t s, const XcorrArgs &a, int row_count, const float2 *twA, const float2 *twB)
+static hipError_t launch_xcorr_lag14(hipStream_t s, const XcorrArgs &a, int row_count, const float2 *twA, const float2 *twB, int *waitflag, bool *used_q)
 {
-    const char variant = k1_variant();
+    static const int cus = [] {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 1) n = 256;
+        const char *e = getenv("CRSDR_K1_QGRID");
+        return e ? atoi(e) : n;
+    }();
+    const int items = row_count * a.nblocks;
+    char variant = k1_variant();
+    // measured (r01, T = 64): q is 3-5 % faster from 128 rows per launch block up (32 items per workgroup), 4 % slower at 21 rows (5 items)
+    if (variant == 'a') variant = items >= 16 * cus ? 'q' : 'p';
+    if (used_q) *used_q = variant == 'q';
     const bool half = variant == 'h';
     if (variant == 'p') {
         auto kp = x14p::k_xcorr_lag14p;
@@ -220,15 +231,8 @@ static hipError_t launch_xcorr_lag14(hipStream_t s, const XcorrArgs &a, int row_
         auto kq = x14p::k_xcorr_lag14q;
         hipError_t eq = hipFuncSetAttribute((const void *)kq, hipFuncAttributeMaxDynamicSharedMemorySize, x14p::LDSQ_BYTES);
         if (eq != hipSuccess) return eq;
-        static const int cus = [] {
-            int dev = 0, n = 0;
-            if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 1) n = 256;
-            const char *e = getenv("CRSDR_K1_QGRID");
-            return e ? atoi(e) : n;
-        }();
-        const int items = row_count * a.nblocks;
         hipLaunchKernelGGL(kq, dim3((unsigned)std::max(1, std::min(cus, (items + 1) / 2))), dim3(2 * x14p::QG), x14p::LDSQ_BYTES, s, a, twA, twB, row_count,
-                           (int *)nullptr);
+                           waitflag);
         return hipGetLastError();
     }
     if (half) {
@@ -608,7 +612,8 @@ struct crsdr_plan {
     long long *d_corr = nullptr;       // [T][nrows][2]: integer sums (three-kernel path) or the fused kernel's two hand-over slots
     int chain_slot = 0;                // fused path: slot [chain_slot] of every entry carries this batch's unit phasors,
     int chain_armed[2] = {0, 0};       // the kernel re-arms the other one; leading blocks of each slot known to be all-ones
-    unsigned int *d_sync = nullptr;    // fused K2: [0] ticket counter, [1] status
+    unsigned int *d_sync = nullptr;    // fused K2: [0] ticket counter, [1] status; [2] two-row K1: waits that ran out
+    bool k1_used = false;              // a two-row K1 launch is (or was) in flight: check [2] at the next sync
     bool fused_k2 = true, fused_used = false;
     int phase_cur = 0;
     int last_nblocks = 0;
@@ -1036,7 +1041,7 @@ extern "C" int crsdr_plan_submit_batch(crsdr_plan *p, const void *rows, int mem_
         }
         hipEvent_t *pe1 = prof_pair(p, CRSDR_KERNEL_XCORR_LAG);
         if (pe1) HIP_TRY(hipEventRecord(pe1[0], KS));
-        if (p->log2n == 14) HIP_TRY(launch_xcorr_lag14(KS, xa, p->row_count, p->d_twA, p->d_twB));
+        if (p->log2n == 14) { bool q = false; HIP_TRY(launch_xcorr_lag14(KS, xa, p->row_count, p->d_twA, p->d_twB, reinterpret_cast<int *>(p->d_sync + 2), &q)); p->k1_used |= q; }
         else HIP_TRY(CRSDR_DISPATCH_LOG2(p->log2n, (launch_xcorr_lag<LG>(KS, xa, p->row_count, p->d_tw))));
         if (pe1) HIP_TRY(hipEventRecord(pe1[1], KS));
         HIP_TRY(hipEventRecord(p->ev_k1done[slot], KS));
@@ -1118,6 +1123,16 @@ extern "C" int crsdr_plan_submit(crsdr_plan *p, const void *rows, int mem_kind, 
 // exact either way; the counter is only kept for diagnostics (CRSDR_K2_DEBUG=1 prints it)
 static int check_fused_status(crsdr_plan *p)
 {
+    // the two-row K1 (xcorr14q.hpp) bounds its waits for the LDS image and its group barriers; one that runs out means a
+    // scheduling assumption failed and the rows of that launch are not to be trusted: an error, never silent
+    if (p->k1_used) {
+        int w = 0;
+        HIP_TRY(hipMemcpy(&w, p->d_sync + 2, sizeof(w), hipMemcpyDeviceToHost));
+        if (w) {
+            (void)hipMemset(p->d_sync + 2, 0, sizeof(w));
+            return fail(CRSDR_EHIP, "xcorr: %d workgroup(s) of the two-row kernel ran out of a bounded wait (results invalid; CRSDR_K1_VARIANT=packed avoids the kernel)", w);
+        }
+    }
     static const bool dbg = [] { const char *e = getenv("CRSDR_K2_DEBUG"); return e && atoi(e) != 0; }();
     if (!p->fused_used || !dbg) return CRSDR_OK;
     unsigned int st = 0;

@@ -20,6 +20,12 @@ namespace x14p {
 constexpr int QG = 256;                                       // threads per row group
 constexpr int LDSQ_BYTES = LDS_ELEMS * 8 + 2 * 512 + 64;      // image + a reduction scratch per group + sync words
 constexpr int kQSpinLimit = 1 << 18;
+#ifndef Q_PRIO
+#define Q_PRIO 3
+#endif
+#ifndef Q_ACQ_SLEEP
+#define Q_ACQ_SLEEP 2
+#endif
 
 struct QSync {
     int owner;      // 0 = image free, else 2 * seq + group + 1
@@ -66,7 +72,7 @@ __device__ __forceinline__ void q_acquire(QSync *s, int tag)
         }
         old = __builtin_amdgcn_readfirstlane(old);
         if (old == 0 || old == tag) break;
-        __builtin_amdgcn_s_sleep(2);
+        __builtin_amdgcn_s_sleep(Q_ACQ_SLEEP);
         if (++spins > kQSpinLimit || __hip_atomic_load(&s->err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) {
             __hip_atomic_store(&s->err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             break;
@@ -202,7 +208,7 @@ __global__ __launch_bounds__(2 * QG, 1) void k_xcorr_lag14q(XcorrArgs a, const f
             q_p0_compute(v, src, twA, a.xor80, vt0);      // no LDS yet: both halves run beside the other group's middle section
             q_p0_compute(v2, src, twA, a.xor80, vt1);
             q_acquire(sy, 2 * k + g + 1);
-            __builtin_amdgcn_s_setprio(3);                // the owner's window is what the pair's period is made of
+            __builtin_amdgcn_s_setprio(Q_PRIO);                // the owner's window is what the pair's period is made of
             q_p0_store(A, v, vt0);
             q_p0_store(A, v2, vt1);
         }

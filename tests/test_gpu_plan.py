@@ -487,7 +487,7 @@ def test_device_input_and_bound_packet_alignments(b, synth, B):
 
 
 def test_k1_variants_agree(tmp_path):
-    # CRSDR_K1_VARIANT: packed (default, xcorr14p.hpp) must equal scalar (xcorr14.hpp) bit for bit; half selects xcorr14h.hpp (two rows per CU, even / odd plane trips through 66 KiB of LDS).
+    # CRSDR_K1_VARIANT: packed (xcorr14p.hpp; the default picks it or the two-row kernel q by launch size) must equal scalar (xcorr14.hpp) bit for bit; half selects xcorr14h.hpp (two rows per CU, even / odd plane trips through 66 KiB of LDS).
     # The variant is chosen once per process, so it runs in a child: same lags, mag within 1e-5 (the last pass is
     # decimation-in-time instead of -in-frequency), same packets except +-1 LSB at rounding boundaries.
     import subprocess, sys, textwrap
@@ -503,11 +503,23 @@ def test_k1_variants_agree(tmp_path):
         plan = b.Plan(nsig + 1, 2 * L, b.MODE_DIGITAL, max_batch=T)
         plan.submit(blocks, seq=3)
         outs = [plan.fetch(block=t) for t in range(T)]
+        # a second, larger launch (several rows per workgroup for the persistent two-row kernel) with a lag mask:
+        # every third row keeps its carried lag (xcorr_skip), two batches so that there is carried state
+        nsig2, T2 = 600, 5
+        params2 = synth.RowParams(nsig2, L, 777, dmax=3000)
+        blocks2 = np.stack([synth.make_block(nsig2, L, 777, t, params=params2)[0] for t in range(T2)])
+        plan2 = b.Plan(nsig2 + 1, 2 * L, b.MODE_DIGITAL, max_batch=T2)
+        mask = (np.arange(nsig2 + 1) %% 3 != 0).astype(np.uint8)
+        plan2.submit(blocks2, seq=0)
+        plan2.submit(blocks2, seq=T2, lag_mask=mask)
+        outs2 = [plan2.fetch(block=t) for t in range(T2)]
         np.savez(sys.argv[1], lag=np.stack([o["lag"] for o in outs]), mag=np.stack([o["mag"] for o in outs]),
-                 frac=np.stack([o["frac"] for o in outs]), packet=np.stack([o["packet"] for o in outs]), d=params.d)
+                 frac=np.stack([o["frac"] for o in outs]), packet=np.stack([o["packet"] for o in outs]), d=params.d,
+                 lag2=np.stack([o["lag"] for o in outs2]), mag2=np.stack([o["mag"] for o in outs2]),
+                 frac2=np.stack([o["frac"] for o in outs2]), d2=params2.d)
     ''') % root
     res = {}
-    for variant in ("scalar", "half", "packed", "q"):
+    for variant in ("scalar", "half", "packed", "q", "auto"):
         out = tmp_path / f"{variant}.npz"
         env = dict(os.environ, CRSDR_K1_VARIANT=variant)
         r = subprocess.run([sys.executable, "-c", code, str(out)], env=env, capture_output=True, text=True, timeout=300)
@@ -518,6 +530,10 @@ def test_k1_variants_agree(tmp_path):
         assert np.array_equal(res["packed"][key].view(np.uint8), res["scalar"][key].view(np.uint8)), key
         # q: the packed passes run by one persistent workgroup per CU, two rows in opposite phases (xcorr14q.hpp)
         assert np.array_equal(res["packed"][key].view(np.uint8), res["q"][key].view(np.uint8)), ("q", key)
+    for key in ("lag2", "mag2", "frac2"):      # 3000 items: "auto" takes the two-row kernel here as well
+        assert np.array_equal(res["packed"][key].view(np.uint8), res["q"][key].view(np.uint8)), ("q", key)
+        assert np.array_equal(res["packed"][key].view(np.uint8), res["auto"][key].view(np.uint8)), ("auto", key)
+    assert np.array_equal(res["q"]["lag2"][0, 1:], res["q"]["d2"])
     f, h = res["scalar"], res["half"]
     assert np.array_equal(h["lag"], f["lag"]) and np.array_equal(h["lag"][0, 1:], f["d"])
     assert np.allclose(h["mag"], f["mag"], rtol=1e-5)
