@@ -34,14 +34,14 @@ struct QSync {
     int err;        // a bounded wait ran out
 };
 
-#ifdef CRSDR_QDEBUG
+#ifdef CRSDR_QDEBUG      // tools/k1_pair.hip: cycles workgroup 0's waves spend in group barriers [1] / waiting for the image [2], total [0]
+__device__ unsigned long long *dbg__ = nullptr;
 #define QDBG_T0 const unsigned long long t0__ = __builtin_readcyclecounter();
 #define QDBG_ADD(slot) if (dbg__ && blockIdx.x == 0 && (threadIdx.x & 63) == 0) atomicAdd(dbg__ + (slot), (unsigned long long)(__builtin_readcyclecounter() - t0__));
 #else
 #define QDBG_T0
 #define QDBG_ADD(slot)
 #endif
-__device__ unsigned long long *dbg__ = nullptr;
 __device__ __forceinline__ void q_barrier(QSync *s, int g, int &gen)
 {
     QDBG_T0
