@@ -113,14 +113,16 @@ __device__ __forceinline__ void q_p0_compute(c2 *v, const int8_t *__restrict__ r
 }
 __device__ __forceinline__ void q_p0_store(c2 *A, const c2 *v, int vt)
 {
-    const int base = p0_base(vt);
+    int base = p0_base(vt);
+    asm volatile("" : "+v"(base));       // formed here, not hoisted out of the row loop and kept (spilled) as 32 addresses
 #pragma unroll
     for (int k = 0; k < 32; ++k) A[base + k * 528] = v[xpos(k)];
 }
 // P0' of one virtual thread: loads, then (separately) the arithmetic down to |.|^2
 __device__ __forceinline__ void q_p0i_load(c2 *v, const c2 *A, int vt)
 {
-    const int base = p0_base(vt);
+    int base = p0_base(vt);
+    asm volatile("" : "+v"(base));
 #pragma unroll
     for (int k = 0; k < 32; ++k) v[k] = A[base + k * 528];
 }
@@ -145,7 +147,9 @@ __device__ __forceinline__ void q_refspec_load(float4 *r, const float4 *__restri
 }
 __device__ __forceinline__ void q_junction_half(float4 *A4, const float4 *r, int vt, int h)
 {
-    const int g = ((vt >> 6) << 7) + 64 * h + (vt & 63), base = j_base(g), key = g & 7;
+    const int g = ((vt >> 6) << 7) + 64 * h + (vt & 63), key = g & 7;
+    int base = j_base(g);
+    asm volatile("" : "+v"(base));
     c2 u[16];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
@@ -195,8 +199,11 @@ __global__ __launch_bounds__(2 * QG, 1) void k_xcorr_lag14q(XcorrArgs a, const f
     const unsigned long long tk0__ = __builtin_readcyclecounter();
 #endif
     const int nitems = row_count * a.nblocks;
-    const int vt0 = tid, vt1 = tid + QG;
     for (int k = 0;; ++k) {
+        // opaque per iteration: otherwise every LDS / table offset derived from the two virtual thread ids is hoisted out
+        // of the row loop and ~40 registers' worth of them live (spilled) across it
+        int vt0 = tid, vt1 = tid + QG;
+        asm volatile("" : "+v"(vt0), "+v"(vt1));
         const int item = (2 * k + g) * (int)gridDim.x + (int)blockIdx.x;
         if (item >= nitems) break;
         const int t = item / row_count, row = a.row_begin + item % row_count;
