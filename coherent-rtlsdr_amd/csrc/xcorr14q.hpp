@@ -42,7 +42,7 @@ __device__ unsigned long long *dbg__ = nullptr;
 #define QDBG_T0
 #define QDBG_ADD(slot)
 #endif
-__device__ __forceinline__ void q_barrier(QSync *s, int g, int &gen)
+__device__ __forceinline__ void q_barrier(QSync *s, int g, int &gen, int site = 0)
 {
     QDBG_T0
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -57,6 +57,7 @@ __device__ __forceinline__ void q_barrier(QSync *s, int g, int &gen)
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     QDBG_ADD(1)
+    QDBG_ADD(3 + site)
 }
 
 __device__ __forceinline__ void q_acquire(QSync *s, int tag)
@@ -223,7 +224,7 @@ __global__ __launch_bounds__(2 * QG, 1) void k_xcorr_lag14q(XcorrArgs a, const f
         tw_load(wB, twB, TWB_STRIDE, tid & 15);
         float4 ra[8], rb[8];
         q_refspec_load(ra, refspec4, vt0, 0);
-        q_barrier(sy, g, gen);
+        q_barrier(sy, g, gen, 0);
         pass1_forward(A, wB, vt0);
         pass1_forward(A, wB, vt1);
         wave_lds_sync();
@@ -237,7 +238,7 @@ __global__ __launch_bounds__(2 * QG, 1) void k_xcorr_lag14q(XcorrArgs a, const f
         wave_lds_sync();
         pass1_inverse(A, wB, vt0);
         pass1_inverse(A, wB, vt1);
-        q_barrier(sy, g, gen);
+        q_barrier(sy, g, gen, 1);
         float m0[32], m1[32];
         {
             c2 v[32], v2[32];
@@ -255,7 +256,7 @@ __global__ __launch_bounds__(2 * QG, 1) void k_xcorr_lag14q(XcorrArgs a, const f
         const float wm = q_wave_max63(tm);
         if (tid == 0) redi[16] = 0x7fffffff;
         if ((tid & 63) == 63) red[tid >> 6] = wm;
-        q_barrier(sy, g, gen);
+        q_barrier(sy, g, gen, 2);
         float gm = red[0];
 #pragma unroll
         for (int wv = 1; wv < QG / 64; ++wv) gm = fmaxf(gm, red[wv]);
@@ -268,7 +269,7 @@ __global__ __launch_bounds__(2 * QG, 1) void k_xcorr_lag14q(XcorrArgs a, const f
             }
             atomicMin(&redi[16], bi);
         }
-        q_barrier(sy, g, gen);
+        q_barrier(sy, g, gen, 3);
         int gi = redi[16];
         if ((unsigned)gi >= (unsigned)N) gi = 0;
         const int pc = gi & 511, pi_ = gi >> 9;
@@ -300,7 +301,7 @@ __global__ __launch_bounds__(2 * QG, 1) void k_xcorr_lag14q(XcorrArgs a, const f
                 for (int i = 0; i < 32; ++i) mr = (i == (nr >> 9)) ? (((nr & 511) >> 8) ? m1[i] : m0[i]) : mr;
                 red[33] = mr;
             }
-            q_barrier(sy, g, gen);
+            q_barrier(sy, g, gen, 4);
             if (tid == 0) {
                 float D = 0.0f;
                 if (gi > 0 && gi < N - 1) {

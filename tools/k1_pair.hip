@@ -28,7 +28,7 @@ int main(int argc, char **argv)
     int32_t *lag, *lag_s; float *mag, *frac, *mag_s, *frac_s;
     CK(hipMalloc(&lag, T * rows * 4)); CK(hipMalloc(&mag, T * rows * 4)); CK(hipMalloc(&frac, T * rows * 4));
     CK(hipMalloc(&lag_s, rows * 4)); CK(hipMalloc(&mag_s, rows * 4)); CK(hipMalloc(&frac_s, rows * 4));
-    unsigned long long *dbg; CK(hipMalloc(&dbg, 64)); CK(hipMemset(dbg, 0, 64));
+    unsigned long long *dbg; CK(hipMalloc(&dbg, 128)); CK(hipMemset(dbg, 0, 128));
     int *err; CK(hipMalloc(&err, 4)); CK(hipMemset(err, 0, 4));
     CK(hipFuncSetAttribute((const void *)x14::k_ref_spectrum14, hipFuncAttributeMaxDynamicSharedMemorySize, x14::LDS_BYTES));
     CK(hipFuncSetAttribute((const void *)x14p::k_xcorr_lag14p, hipFuncAttributeMaxDynamicSharedMemorySize, x14::LDS_BYTES));
@@ -55,9 +55,10 @@ int main(int argc, char **argv)
     }
     CK(hipMemcpy(lag_q.data(), lag, lag_q.size() * 4, hipMemcpyDeviceToHost));
     int herr = 0; CK(hipMemcpy(&herr, err, 4, hipMemcpyDeviceToHost));
-    unsigned long long hd[8]; CK(hipMemcpy(hd, dbg, 64, hipMemcpyDeviceToHost));
+    unsigned long long hd[16]; CK(hipMemcpy(hd, dbg, 128, hipMemcpyDeviceToHost));
     printf("same lags: %s, wait errors: %d\n", lag_p == lag_q ? "yes" : "NO", herr);
     printf("workgroup 0, summed over its 8 waves: total %.0f cycles, in group barriers %.0f (%.1f %%), waiting for the image %.0f (%.1f %%)\n",
            (double)hd[0], (double)hd[1], 100.0 * hd[1] / hd[0], (double)hd[2], 100.0 * hd[2] / hd[0]);
+    printf("barrier sites (P0->P1, P1'->P0', max, index, edge): %.1f %.1f %.1f %.1f %.1f %% of wave time\n", 100.0 * hd[3] / hd[0], 100.0 * hd[4] / hd[0], 100.0 * hd[5] / hd[0], 100.0 * hd[6] / hd[0], 100.0 * hd[7] / hd[0]);
     return 0;
 }
