@@ -211,17 +211,17 @@ __global__ __launch_bounds__(2 * QG, 1) void k_xcorr_lag14q(XcorrArgs a, const f
         if (xcorr_skip(a, row, t, tid)) continue;
         const int8_t *src = a.rows + (size_t)t * a.block_stride + (size_t)row * N;
         const float4 *__restrict__ refspec4 = reinterpret_cast<const float4 *>(a.refspec) + (size_t)t * (N / 2);
+        c2 wB[32];
         {
             c2 v[32], v2[32];
             q_p0_compute(v, src, twA, a.xor80, vt0);      // no LDS yet: both halves run beside the other group's middle section
             q_p0_compute(v2, src, twA, a.xor80, vt1);
+            tw_load(wB, twB, TWB_STRIDE, tid & 15);       // P1 / P1' twiddles: table loads and product chain outside the ownership window
             q_acquire(sy, 2 * k + g + 1);
             __builtin_amdgcn_s_setprio(Q_PRIO);                // the owner's window is what the pair's period is made of
             q_p0_store(A, v, vt0);
             q_p0_store(A, v2, vt1);
         }
-        c2 wB[32];
-        tw_load(wB, twB, TWB_STRIDE, tid & 15);
         float4 ra[8], rb[8];
         q_refspec_load(ra, refspec4, vt0, 0);
         q_barrier(sy, g, gen, 0);

@@ -46,13 +46,15 @@ int main(int argc, char **argv)
     }
     std::vector<int32_t> lag_p((size_t)T * rows), lag_q((size_t)T * rows);
     CK(hipMemcpy(lag_p.data(), lag, lag_p.size() * 4, hipMemcpyDeviceToHost));
-    for (int rep = 0; rep < 2; ++rep) {
+    float best = 1e9f;
+    for (int rep = 0; rep < 8; ++rep) {
         unsigned long long *null = nullptr;
-        CK(hipMemcpyToSymbol(HIP_SYMBOL(x14p::dbg__), rep ? &dbg : &null, sizeof(dbg)));
+        CK(hipMemcpyToSymbol(HIP_SYMBOL(x14p::dbg__), rep == 7 ? &dbg : &null, sizeof(dbg)));
         CK(hipEventRecord(e0)); hipLaunchKernelGGL(x14p::k_xcorr_lag14q, dim3(grid), dim3(512), x14p::LDSQ_BYTES, 0, xa, twA, twB, rows - 1, err); CK(hipEventRecord(e1));
         CK(hipEventSynchronize(e1)); CK(hipEventElapsedTime(&ms, e0, e1));
-        printf("pair, two rows per CU  : %.3f ms (%.2f us per row and CU)\n", ms, ms * 1e3 / ((rows - 1) * T / (double)grid));
+        if (rep && rep < 7) best = std::min(best, ms);
     }
+    printf("pair, two rows per CU  : best of 6 %.3f ms (%.2f us per row and CU)\n", best, best * 1e3 / ((rows - 1) * T / (double)grid));
     CK(hipMemcpy(lag_q.data(), lag, lag_q.size() * 4, hipMemcpyDeviceToHost));
     int herr = 0; CK(hipMemcpy(&herr, err, 4, hipMemcpyDeviceToHost));
     unsigned long long hd[16]; CK(hipMemcpy(hd, dbg, 128, hipMemcpyDeviceToHost));
