@@ -206,7 +206,8 @@ static hipError_t launch_ref_spectrum14(hipStream_t s, int nblocks, const int8_t
     return hipGetLastError();
 }
 
-static hipError_t launch_xcorr_lag14(hipStream_t s, const XcorrArgs &a, int row_count, const float2 *twA, const float2 *twB, int *waitflag, bool *used_q)
+static hipError_t launch_xcorr_lag14(hipStream_t s, const XcorrArgs &a, int row_count, const float2 *twA, const float2 *twB, int *waitflag, bool *used_q,
+                                     unsigned int *work, unsigned int *work_base)
 {
     static const int cus = [] {
         int dev = 0, n = 0;
@@ -232,7 +233,8 @@ static hipError_t launch_xcorr_lag14(hipStream_t s, const XcorrArgs &a, int row_
         hipError_t eq = hipFuncSetAttribute((const void *)kq, hipFuncAttributeMaxDynamicSharedMemorySize, x14p::LDSQ_BYTES);
         if (eq != hipSuccess) return eq;
         hipLaunchKernelGGL(kq, dim3((unsigned)std::max(1, std::min(cus, (items + 1) / 2))), dim3(2 * x14p::QG), x14p::LDSQ_BYTES, s, a, twA, twB, row_count,
-                           waitflag);
+                           waitflag, work, *work_base);
+        *work_base += (unsigned)items;      // the launch advances the device counter by exactly its item count (xcorr14q.hpp)
         return hipGetLastError();
     }
     if (half) {
@@ -613,6 +615,7 @@ struct crsdr_plan {
     int chain_slot = 0;                // fused path: slot [chain_slot] of every entry carries this batch's unit phasors,
     int chain_armed[2] = {0, 0};       // the kernel re-arms the other one; leading blocks of each slot known to be all-ones
     unsigned int *d_sync = nullptr;    // fused K2: [0] ticket counter, [1] status; [2] two-row K1: waits that ran out
+    unsigned int q_work_base = 0;      // value of the two-row K1's work counter (d_sync[3]) when the next launch starts
     bool k1_used = false;              // a two-row K1 launch is (or was) in flight: check [2] at the next sync
     bool fused_k2 = true, fused_used = false;
     int phase_cur = 0;
@@ -1041,7 +1044,7 @@ extern "C" int crsdr_plan_submit_batch(crsdr_plan *p, const void *rows, int mem_
         }
         hipEvent_t *pe1 = prof_pair(p, CRSDR_KERNEL_XCORR_LAG);
         if (pe1) HIP_TRY(hipEventRecord(pe1[0], KS));
-        if (p->log2n == 14) { bool q = false; HIP_TRY(launch_xcorr_lag14(KS, xa, p->row_count, p->d_twA, p->d_twB, reinterpret_cast<int *>(p->d_sync + 2), &q)); p->k1_used |= q; }
+        if (p->log2n == 14) { bool q = false; HIP_TRY(launch_xcorr_lag14(KS, xa, p->row_count, p->d_twA, p->d_twB, reinterpret_cast<int *>(p->d_sync + 2), &q, p->d_sync + 3, &p->q_work_base)); p->k1_used |= q; }
         else HIP_TRY(CRSDR_DISPATCH_LOG2(p->log2n, (launch_xcorr_lag<LG>(KS, xa, p->row_count, p->d_tw))));
         if (pe1) HIP_TRY(hipEventRecord(pe1[1], KS));
         HIP_TRY(hipEventRecord(p->ev_k1done[slot], KS));
@@ -1129,7 +1132,8 @@ static int check_fused_status(crsdr_plan *p)
         int w = 0;
         HIP_TRY(hipMemcpy(&w, p->d_sync + 2, sizeof(w), hipMemcpyDeviceToHost));
         if (w) {
-            (void)hipMemset(p->d_sync + 2, 0, sizeof(w));
+            (void)hipMemset(p->d_sync + 2, 0, 2 * sizeof(w));     // the flag and the work counter (its count is off after a failed launch)
+            p->q_work_base = 0;
             return fail(CRSDR_EHIP, "xcorr: %d workgroup(s) of the two-row kernel ran out of a bounded wait (results invalid; CRSDR_K1_VARIANT=packed avoids the kernel)", w);
         }
     }

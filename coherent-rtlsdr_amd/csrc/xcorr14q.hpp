@@ -18,7 +18,7 @@ namespace crsdr {
 namespace x14p {
 
 constexpr int QG = 256;                                       // threads per row group
-constexpr int LDSQ_BYTES = LDS_ELEMS * 8 + 2 * 512 + 64;      // image + a reduction scratch per group + sync words
+constexpr int LDSQ_BYTES = LDS_ELEMS * 8 + 2 * 512 + 64;      // image + a reduction scratch per group + sync words (sizeof(QSync) <= 64)
 constexpr int kQSpinLimit = 1 << 18;
 #ifndef Q_PRIO
 #define Q_PRIO 3
@@ -32,6 +32,7 @@ struct QSync {
     int relcnt;     // waves of the owner group that hold their P0' values
     int bar[2];     // arrivals at each group's barrier (monotonic)
     int err;        // a bounded wait ran out
+    int next[2];    // the item each group takes after its current one (drawn one row ahead by the group's first lane)
 };
 
 #ifdef CRSDR_QDEBUG      // tools/k1_pair.hip: cycles workgroup 0's waves spend in group barriers [1] / waiting for the image [2], total [0]
@@ -183,7 +184,8 @@ __device__ __forceinline__ float q_wave_max63(float wm)
 
 // grid: one workgroup per CU; items = owned rows x blocks, item (2k + g) * gridDim.x + blockIdx.x goes to group g
 __global__ __launch_bounds__(2 * QG, 1) void k_xcorr_lag14q(XcorrArgs a, const float2 *__restrict__ twA_, const float2 *__restrict__ twB_,
-                                                           int row_count, int *__restrict__ errflag)
+                                                           int row_count, int *__restrict__ errflag, unsigned int *__restrict__ work,
+                                                           unsigned int work_base)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const c2 *twA = reinterpret_cast<const c2 *>(twA_), *twB = reinterpret_cast<const c2 *>(twB_);
@@ -193,22 +195,33 @@ __global__ __launch_bounds__(2 * QG, 1) void k_xcorr_lag14q(XcorrArgs a, const f
     float *red = reinterpret_cast<float *>(smem + (size_t)LDS_ELEMS * 8 + 512 * g);
     int *redi = reinterpret_cast<int *>(red);
     QSync *sy = reinterpret_cast<QSync *>(smem + (size_t)LDS_ELEMS * 8 + 1024);
-    if (threadIdx.x == 0) { sy->owner = 0; sy->relcnt = 0; sy->bar[0] = 0; sy->bar[1] = 0; sy->err = 0; }
+    if (threadIdx.x == 0) { sy->owner = 0; sy->relcnt = 0; sy->bar[0] = 0; sy->bar[1] = 0; sy->err = 0; sy->next[0] = 0; sy->next[1] = 0; }
     __syncthreads();
     int gen = 0;
 #ifdef CRSDR_QDEBUG
     const unsigned long long tk0__ = __builtin_readcyclecounter();
 #endif
     const int nitems = row_count * a.nblocks;
+    // Work order: each group starts on item g * gridDim.x + blockIdx.x and draws every further one from a global counter
+    // (*work counts on from work_base; it advances by exactly nitems per launch -- every item after the first 2 * grid
+    // is one draw, and every group that had an item makes one draw that comes back empty -- so the host never resets it).
+    // A workgroup that gets its CU late (a collective's kernel, K0 or another process is resident there) then simply takes
+    // fewer rows; with a fixed share per workgroup it would run its whole share after everybody else had finished.
+    int item = g * (int)gridDim.x + (int)blockIdx.x;
     for (int k = 0;; ++k) {
         // opaque per iteration: otherwise every LDS / table offset derived from the two virtual thread ids is hoisted out
         // of the row loop and ~40 registers' worth of them live (spilled) across it
         int vt0 = tid, vt1 = tid + QG;
         asm volatile("" : "+v"(vt0), "+v"(vt1));
-        const int item = (2 * k + g) * (int)gridDim.x + (int)blockIdx.x;
         if (item >= nitems) break;
         const int t = item / row_count, row = a.row_begin + item % row_count;
-        if (xcorr_skip(a, row, t, tid)) continue;
+        if (xcorr_skip(a, row, t, tid)) {
+            q_barrier(sy, g, gen, 5);           // every wave of the group has read this item from next[g] before it is overwritten
+            if (tid == 0) sy->next[g] = 2 * (int)gridDim.x + (int)(atomicAdd(work, 1u) - work_base);
+            q_barrier(sy, g, gen, 5);
+            item = sy->next[g];                 // (the next write follows a group barrier on either path)
+            continue;
+        }
         const int8_t *src = a.rows + (size_t)t * a.block_stride + (size_t)row * N;
         const float4 *__restrict__ refspec4 = reinterpret_cast<const float4 *>(a.refspec) + (size_t)t * (N / 2);
         c2 wB[32];
@@ -239,6 +252,7 @@ __global__ __launch_bounds__(2 * QG, 1) void k_xcorr_lag14q(XcorrArgs a, const f
         pass1_inverse(A, wB, vt0);
         pass1_inverse(A, wB, vt1);
         q_barrier(sy, g, gen, 1);
+        if (tid == 0) sy->next[g] = 2 * (int)gridDim.x + (int)(atomicAdd(work, 1u) - work_base);   // read after this row's last barrier
         float m0[32], m1[32];
         {
             c2 v[32], v2[32];
@@ -312,6 +326,7 @@ __global__ __launch_bounds__(2 * QG, 1) void k_xcorr_lag14q(XcorrArgs a, const f
                 xcorr_publish(a, row, t, gi - L, sqrtf(gm / (float)L) * kInvScale2, D);
             }
         }
+        item = sy->next[g];       // drawn after this row's second barrier, read after its last one
     }
 #ifdef CRSDR_QDEBUG
     if (dbg__ && blockIdx.x == 0 && (threadIdx.x & 63) == 0) atomicAdd(dbg__ + 0, (unsigned long long)(__builtin_readcyclecounter() - tk0__));

@@ -30,12 +30,20 @@ int main(int argc, char **argv)
     CK(hipMalloc(&lag_s, rows * 4)); CK(hipMalloc(&mag_s, rows * 4)); CK(hipMalloc(&frac_s, rows * 4));
     unsigned long long *dbg; CK(hipMalloc(&dbg, 128)); CK(hipMemset(dbg, 0, 128));
     int *err; CK(hipMalloc(&err, 4)); CK(hipMemset(err, 0, 4));
+    unsigned int *work; CK(hipMalloc(&work, 4)); CK(hipMemset(work, 0, 4));
     CK(hipFuncSetAttribute((const void *)x14::k_ref_spectrum14, hipFuncAttributeMaxDynamicSharedMemorySize, x14::LDS_BYTES));
     CK(hipFuncSetAttribute((const void *)x14p::k_xcorr_lag14p, hipFuncAttributeMaxDynamicSharedMemorySize, x14::LDS_BYTES));
     CK(hipFuncSetAttribute((const void *)x14p::k_xcorr_lag14q, hipFuncAttributeMaxDynamicSharedMemorySize, x14p::LDSQ_BYTES));
     hipLaunchKernelGGL(x14::k_ref_spectrum14, dim3(T), dim3(512), x14::LDS_BYTES, 0, d_rows, (size_t)rows * N, twA, twB, (float4 *)refspec, 0u);
+    uint8_t *d_mask = nullptr;
+    if (argc > 3 && atoi(argv[3])) {
+        std::vector<uint8_t> hm(rows);
+        for (int r = 0; r < rows; ++r) hm[r] = (r % 3) != 0;
+        CK(hipMalloc(&d_mask, rows)); CK(hipMemcpy(d_mask, hm.data(), rows, hipMemcpyHostToDevice));
+        CK(hipMemset(lag_s, 0, rows * 4)); CK(hipMemset(mag_s, 0, rows * 4)); CK(hipMemset(frac_s, 0, rows * 4));
+    }
     XcorrArgs xa{};
-    xa.rows = d_rows; xa.block_stride = (size_t)rows * N; xa.refspec = refspec; xa.lag_mask = nullptr; xa.row_begin = 1; xa.nrows = rows;
+    xa.rows = d_rows; xa.block_stride = (size_t)rows * N; xa.refspec = refspec; xa.lag_mask = d_mask; xa.row_begin = 1; xa.nrows = rows;
     xa.nblocks = T; xa.xor80 = 0; xa.lag = lag; xa.mag = mag; xa.frac = frac; xa.lag_state = lag_s; xa.mag_state = mag_s; xa.frac_state = frac_s;
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     float ms;
@@ -50,7 +58,7 @@ int main(int argc, char **argv)
     for (int rep = 0; rep < 8; ++rep) {
         unsigned long long *null = nullptr;
         CK(hipMemcpyToSymbol(HIP_SYMBOL(x14p::dbg__), rep == 7 ? &dbg : &null, sizeof(dbg)));
-        CK(hipEventRecord(e0)); hipLaunchKernelGGL(x14p::k_xcorr_lag14q, dim3(grid), dim3(512), x14p::LDSQ_BYTES, 0, xa, twA, twB, rows - 1, err); CK(hipEventRecord(e1));
+        CK(hipEventRecord(e0)); hipLaunchKernelGGL(x14p::k_xcorr_lag14q, dim3(grid), dim3(512), x14p::LDSQ_BYTES, 0, xa, twA, twB, rows - 1, err, work, (unsigned)(rep * (rows - 1) * T)); CK(hipEventRecord(e1));
         CK(hipEventSynchronize(e1)); CK(hipEventElapsedTime(&ms, e0, e1));
         if (rep && rep < 7) best = std::min(best, ms);
     }
