@@ -217,8 +217,9 @@ static hipError_t launch_xcorr_lag14(hipStream_t s, const XcorrArgs &a, int row_
     }();
     const int items = row_count * a.nblocks;
     char variant = k1_variant();
-    // measured (r01, T = 64): q is 3-5 % faster from 128 rows per launch block up (32 items per workgroup), 4 % slower at 21 rows (5 items)
-    if (variant == 'a') variant = items >= 16 * cus ? 'q' : 'p';
+    // measured (r01, T = 64): q is 3-7 % faster at 1024 / 256 / 128 / 96 / 48 rows per block (256 ... 12 rows per CU and launch),
+    // 1.4 % at 64, level with p at 32 and 21 rows (8 and 5 per CU)
+    if (variant == 'a') variant = items >= 12 * cus ? 'q' : 'p';
     if (used_q) *used_q = variant == 'q';
     const bool half = variant == 'h';
     if (variant == 'p') {
