@@ -1,5 +1,6 @@
 // k1_pair.hip -- diagnostic build of the two-rows-per-CU K1 (xcorr14q.hpp) beside the packed one: launch time, and how
 // long workgroup 0's waves sit in group barriers / wait for the LDS image.  Never part of the product.
+// Usage: k1_pair [blocks = 16] [workgroups = 256] [mask every third row = 0] [co-resident hog workgroups = 0]
 // Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fno-slp-vectorize -I coherent-rtlsdr_amd/csrc -o tools/k1_pair tools/k1_pair.hip
 #include <hip/hip_runtime.h>
 #include <cstdio>
