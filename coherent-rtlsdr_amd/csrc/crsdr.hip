@@ -233,8 +233,9 @@ static hipError_t launch_xcorr_lag14(hipStream_t s, const XcorrArgs &a, int row_
         auto kq = x14p::k_xcorr_lag14q;
         hipError_t eq = hipFuncSetAttribute((const void *)kq, hipFuncAttributeMaxDynamicSharedMemorySize, x14p::LDSQ_BYTES);
         if (eq != hipSuccess) return eq;
+        static const int qspin = [] { const char *e = getenv("CRSDR_K1_QSPIN"); return e ? atoi(e) : x14p::kQSpinLimit; }();   // polls per wait; tests force 0
         hipLaunchKernelGGL(kq, dim3((unsigned)std::max(1, std::min(cus, (items + 1) / 2))), dim3(2 * x14p::QG), x14p::LDSQ_BYTES, s, a, twA, twB, row_count,
-                           waitflag, work, *work_base);
+                           waitflag, work, *work_base, qspin);
         *work_base += (unsigned)items;      // the launch advances the device counter by exactly its item count (xcorr14q.hpp)
         return hipGetLastError();
     }

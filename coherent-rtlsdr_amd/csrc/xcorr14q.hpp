@@ -33,6 +33,7 @@ struct QSync {
     int bar[2];     // arrivals at each group's barrier (monotonic)
     int err;        // a bounded wait ran out
     int next[2];    // the item each group takes after its current one (drawn one row ahead by the group's first lane)
+    int spin_limit; // polls a wait may take (kQSpinLimit; a test forces 0 to see the error path)
 };
 
 #ifdef CRSDR_QDEBUG      // tools/k1_pair.hip: cycles workgroup 0's waves spend in group barriers [1] / waiting for the image [2], total [0]
@@ -51,7 +52,7 @@ __device__ __forceinline__ void q_barrier(QSync *s, int g, int &gen, int site = 
     gen += QG / 64;
     int spins = 0;
     while (__hip_atomic_load(&s->bar[g], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < gen) {
-        if (++spins > kQSpinLimit || __hip_atomic_load(&s->err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) {
+        if (++spins > s->spin_limit || __hip_atomic_load(&s->err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) {
             __hip_atomic_store(&s->err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             break;
         }
@@ -75,7 +76,7 @@ __device__ __forceinline__ void q_acquire(QSync *s, int tag)
         old = __builtin_amdgcn_readfirstlane(old);
         if (old == 0 || old == tag) break;
         __builtin_amdgcn_s_sleep(Q_ACQ_SLEEP);
-        if (++spins > kQSpinLimit || __hip_atomic_load(&s->err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) {
+        if (++spins > s->spin_limit || __hip_atomic_load(&s->err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) {
             __hip_atomic_store(&s->err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             break;
         }
@@ -185,7 +186,7 @@ __device__ __forceinline__ float q_wave_max63(float wm)
 // grid: one workgroup per CU; items = owned rows x blocks, item (2k + g) * gridDim.x + blockIdx.x goes to group g
 __global__ __launch_bounds__(2 * QG, 1) void k_xcorr_lag14q(XcorrArgs a, const float2 *__restrict__ twA_, const float2 *__restrict__ twB_,
                                                            int row_count, int *__restrict__ errflag, unsigned int *__restrict__ work,
-                                                           unsigned int work_base)
+                                                           unsigned int work_base, int spin_limit)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const c2 *twA = reinterpret_cast<const c2 *>(twA_), *twB = reinterpret_cast<const c2 *>(twB_);
@@ -195,7 +196,7 @@ __global__ __launch_bounds__(2 * QG, 1) void k_xcorr_lag14q(XcorrArgs a, const f
     float *red = reinterpret_cast<float *>(smem + (size_t)LDS_ELEMS * 8 + 512 * g);
     int *redi = reinterpret_cast<int *>(red);
     QSync *sy = reinterpret_cast<QSync *>(smem + (size_t)LDS_ELEMS * 8 + 1024);
-    if (threadIdx.x == 0) { sy->owner = 0; sy->relcnt = 0; sy->bar[0] = 0; sy->bar[1] = 0; sy->err = 0; sy->next[0] = 0; sy->next[1] = 0; }
+    if (threadIdx.x == 0) { sy->owner = 0; sy->relcnt = 0; sy->bar[0] = 0; sy->bar[1] = 0; sy->err = 0; sy->next[0] = 0; sy->next[1] = 0; sy->spin_limit = spin_limit; }
     __syncthreads();
     int gen = 0;
 #ifdef CRSDR_QDEBUG

@@ -542,6 +542,38 @@ def test_k1_variants_agree(tmp_path):
     assert np.abs(d).max() <= 1 and np.count_nonzero(d) <= 1e-4 * d.size
 
 
+def test_two_row_kernel_reports_a_wait_that_ran_out(tmp_path):
+    # the two-row K1 (xcorr14q.hpp) bounds every wait for the LDS image / its group barriers.  With the bound forced to
+    # zero polls (CRSDR_K1_QSPIN=0) waits do run out: the launch must terminate, the next sync / fetch must return an
+    # error (never silent garbage), and the plan must be usable again afterwards -- checked in a child process.
+    import subprocess, sys, textwrap
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = textwrap.dedent('''
+        import importlib, sys, numpy as np
+        sys.path.insert(0, %r)
+        pkg = importlib.import_module("coherent-rtlsdr_amd")
+        b, synth = pkg.binding, pkg.synth
+        nsig, L, T = 300, 8192, 4
+        params = synth.RowParams(nsig, L, 99, dmax=1000)
+        blocks = np.stack([synth.make_block(nsig, L, 99, t, params=params)[0] for t in range(T)])
+        plan = b.Plan(nsig + 1, 2 * L, b.MODE_DIGITAL, max_batch=T)
+        plan.submit(blocks, seq=0)
+        try:
+            plan.fetch(block=0)
+            print("NOERROR")
+        except b.CrsdrError as e:
+            print("ERROR", e)
+    ''') % root
+    env = dict(os.environ, CRSDR_K1_VARIANT="q", CRSDR_K1_QSPIN="0")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "ERROR" in r.stdout and "bounded wait" in r.stdout, r.stdout + r.stderr
+    # the same launch with the normal bound is clean and exact
+    env = dict(os.environ, CRSDR_K1_VARIANT="q")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "NOERROR" in r.stdout, r.stdout + r.stderr
+
+
 def test_plan_lifecycle_does_not_leak_device_memory(b, synth):
     # create / submit / destroy in a loop (all three kernel families: generic, 16384, long-block): device memory
     # in use returns to where it started (the plan owns every device allocation, src/ccoherent.cc:100-110)

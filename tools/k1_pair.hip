@@ -69,7 +69,7 @@ int main(int argc, char **argv)
         if (hogs) { hipLaunchKernelGGL(k_hog, dim3(hogs), dim3(256), 0, hs, 1000000LL /* ~0.45 ms */, err); }
         unsigned long long *null = nullptr;
         CK(hipMemcpyToSymbol(HIP_SYMBOL(x14p::dbg__), rep == 7 ? &dbg : &null, sizeof(dbg)));
-        CK(hipEventRecord(e0)); hipLaunchKernelGGL(x14p::k_xcorr_lag14q, dim3(grid), dim3(512), x14p::LDSQ_BYTES, 0, xa, twA, twB, rows - 1, err, work, (unsigned)(rep * (rows - 1) * T)); CK(hipEventRecord(e1));
+        CK(hipEventRecord(e0)); hipLaunchKernelGGL(x14p::k_xcorr_lag14q, dim3(grid), dim3(512), x14p::LDSQ_BYTES, 0, xa, twA, twB, rows - 1, err, work, (unsigned)(rep * (rows - 1) * T), x14p::kQSpinLimit); CK(hipEventRecord(e1));
         CK(hipEventSynchronize(e1)); CK(hipEventElapsedTime(&ms, e0, e1));
         if (rep && rep < 7) best = std::min(best, ms);
         CK(hipStreamSynchronize(hs));
