@@ -11,6 +11,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <mutex>
 #include <new>
 #include <vector>
@@ -207,7 +208,7 @@ static hipError_t launch_ref_spectrum14(hipStream_t s, int nblocks, const int8_t
 }
 
 static hipError_t launch_xcorr_lag14(hipStream_t s, const XcorrArgs &a, int row_count, const float2 *twA, const float2 *twB, int *waitflag, bool *used_q,
-                                     unsigned int *work, unsigned int *work_base)
+                                     unsigned int *work, unsigned int *work_base, bool allow_q, const std::function<hipError_t()> &before_q)
 {
     static const int cus = [] {
         int dev = 0, n = 0;
@@ -220,6 +221,7 @@ static hipError_t launch_xcorr_lag14(hipStream_t s, const XcorrArgs &a, int row_
     // measured (r01, T = 64): q is 3-7 % faster at 1024 / 256 / 128 / 96 / 48 rows per block (256 ... 12 rows per CU and launch),
     // 1.4 % at 64, level with p at 32 and 21 rows (8 and 5 per CU)
     if (variant == 'a') variant = items >= 12 * cus ? 'q' : 'p';
+    if (variant == 'q' && !allow_q) variant = 'p';   // a plan whose two-row kernel once ran out of a bounded wait stays on the packed kernel
     if (used_q) *used_q = variant == 'q';
     const bool half = variant == 'h';
     if (variant == 'p') {
@@ -234,10 +236,12 @@ static hipError_t launch_xcorr_lag14(hipStream_t s, const XcorrArgs &a, int row_
         hipError_t eq = hipFuncSetAttribute((const void *)kq, hipFuncAttributeMaxDynamicSharedMemorySize, x14p::LDSQ_BYTES);
         if (eq != hipSuccess) return eq;
         static const int qspin = [] { const char *e = getenv("CRSDR_K1_QSPIN"); return e ? atoi(e) : x14p::kQSpinLimit; }();   // polls per wait; tests force 0
+        if (before_q) { hipError_t eb = before_q(); if (eb != hipSuccess) return eb; }   // snapshot of the carried state (rollback on a wait that ran out)
         hipLaunchKernelGGL(kq, dim3((unsigned)std::max(1, std::min(cus, (items + 1) / 2))), dim3(2 * x14p::QG), x14p::LDSQ_BYTES, s, a, twA, twB, row_count,
                            waitflag, work, *work_base, qspin);
-        *work_base += (unsigned)items;      // the launch advances the device counter by exactly its item count (xcorr14q.hpp)
-        return hipGetLastError();
+        const hipError_t el = hipGetLastError();
+        if (el == hipSuccess) *work_base += (unsigned)items;      // a launch that ran advances the device counter by exactly its item count (xcorr14q.hpp)
+        return el;
     }
     if (half) {
         auto kh = x14h::k_xcorr_lag14h;
@@ -619,6 +623,13 @@ struct crsdr_plan {
     unsigned int *d_sync = nullptr;    // fused K2: [0] ticket counter, [1] status; [2] two-row K1: waits that ran out
     unsigned int q_work_base = 0;      // value of the two-row K1's work counter (d_sync[3]) when the next launch starts
     bool k1_used = false;              // a two-row K1 launch is (or was) in flight: check [2] at the next sync
+    // carried state {lag, mag, frac}_state + phase_state[0..1] lives in ONE allocation (d_state) so that the first two-row
+    // launch after a clean status check can snapshot it with one stream-ordered copy; a wait that ran out rolls the
+    // plan back to that snapshot (check_fused_status) and keeps later launches on the packed kernel
+    uint8_t *d_state = nullptr, *d_state_snap = nullptr;
+    size_t state_bytes = 0;
+    bool snap_valid = false, q_disabled = false;
+    int snap_phase_cur = 0;
     bool fused_k2 = true, fused_used = false;
     int phase_cur = 0;
     int last_nblocks = 0;
@@ -670,6 +681,7 @@ static int plan_init_state(crsdr_plan *p)
     p->chain_armed[0] = p->chain_armed[1] = (int)T;
     p->phase_cur = 0;
     p->last_nblocks = 0;
+    p->snap_valid = false;
     return CRSDR_OK;
 }
 
@@ -726,10 +738,17 @@ static int plan_alloc(crsdr_plan *p)
     HIP_TRY(hipMalloc((void **)&p->d_sync, 64));
     HIP_TRY(hipMemset(p->d_sync, 0, 64));
     { const char *e = getenv("CRSDR_K2_FUSED"); if (e) p->fused_k2 = atoi(e) != 0; }
-    HIP_TRY(hipMalloc((void **)&p->d_lag_state, sizeof(int32_t) * n));
-    HIP_TRY(hipMalloc((void **)&p->d_mag_state, sizeof(float) * n));
-    HIP_TRY(hipMalloc((void **)&p->d_frac_state, sizeof(float) * n));
-    for (int i = 0; i < 2; ++i) HIP_TRY(hipMalloc((void **)&p->d_phase_state[i], sizeof(float2) * n));
+    {
+        const size_t n8 = (n + 1) / 2 * 2;                   // keeps the float2 arrays 8-byte aligned
+        p->state_bytes = n8 * (3 * 4 + 2 * 8);
+        HIP_TRY(hipMalloc((void **)&p->d_state, p->state_bytes));
+        HIP_TRY(hipMalloc((void **)&p->d_state_snap, p->state_bytes));
+        p->d_phase_state[0] = reinterpret_cast<float2 *>(p->d_state);
+        p->d_phase_state[1] = p->d_phase_state[0] + n8;
+        p->d_lag_state = reinterpret_cast<int32_t *>(p->d_phase_state[1] + n8);
+        p->d_mag_state = reinterpret_cast<float *>(p->d_lag_state + n8);
+        p->d_frac_state = p->d_mag_state + n8;
+    }
     HIP_TRY(hipHostMalloc((void **)&p->h_readcnt, sizeof(uint32_t) * n * T * kStageSlots, hipHostMallocDefault));
     HIP_TRY(hipHostMalloc((void **)&p->h_mask, n * kStageSlots, hipHostMallocDefault));
     return plan_init_state(p);
@@ -743,8 +762,7 @@ static void plan_free(crsdr_plan *p)
     if (p->aux) (void)hipStreamSynchronize(p->aux);
     if (p->xs) (void)hipStreamSynchronize(p->xs);
     void *bufs[] = {p->d_wc, p->d_wf, p->d_tw1, p->d_Y, p->d_Yref, p->d_part, p->d_tw, p->d_twA, p->d_twB, p->d_refspec[0], p->d_refspec[1], p->d_rows, p->d_packet_alloc, p->d_readcnt,
-                    p->d_mask, p->d_lag, p->d_mag, p->d_frac, p->d_phasor, p->d_corr, p->d_sync, p->d_lag_state, p->d_mag_state,
-                    p->d_frac_state, p->d_phase_state[0], p->d_phase_state[1]};
+                    p->d_mask, p->d_lag, p->d_mag, p->d_frac, p->d_phasor, p->d_corr, p->d_sync, p->d_state, p->d_state_snap};
     for (void *b : bufs) if (b) (void)hipFree(b);
     if (p->h_readcnt) (void)hipHostFree(p->h_readcnt);
     if (p->h_mask) (void)hipHostFree(p->h_mask);
@@ -1046,7 +1064,21 @@ extern "C" int crsdr_plan_submit_batch(crsdr_plan *p, const void *rows, int mem_
         }
         hipEvent_t *pe1 = prof_pair(p, CRSDR_KERNEL_XCORR_LAG);
         if (pe1) HIP_TRY(hipEventRecord(pe1[0], KS));
-        if (p->log2n == 14) { bool q = false; HIP_TRY(launch_xcorr_lag14(KS, xa, p->row_count, p->d_twA, p->d_twB, reinterpret_cast<int *>(p->d_sync + 2), &q, p->d_sync + 3, &p->q_work_base)); p->k1_used |= q; }
+        if (p->log2n == 14) {
+            bool q = false;
+            // the first two-row launch since the last clean status check snapshots the carried state (one 28 B/row copy,
+            // ordered after the previous batch's kernels on this stream): what a wait that ran out is rolled back to
+            auto snapshot = [p, KS]() -> hipError_t {
+                if (p->snap_valid) return hipSuccess;
+                p->snap_valid = true;
+                p->snap_phase_cur = p->phase_cur;
+                return hipMemcpyAsync(p->d_state_snap, p->d_state, p->state_bytes, hipMemcpyDeviceToDevice, KS);
+            };
+            // (with K1 on its own stream the phase kernel of the previous batch may still be writing the state: packed kernel there)
+            HIP_TRY(launch_xcorr_lag14(KS, xa, p->row_count, p->d_twA, p->d_twB, reinterpret_cast<int *>(p->d_sync + 2), &q, p->d_sync + 3, &p->q_work_base,
+                                       !p->q_disabled && !use_x, snapshot));
+            p->k1_used |= q;
+        }
         else HIP_TRY(CRSDR_DISPATCH_LOG2(p->log2n, (launch_xcorr_lag<LG>(KS, xa, p->row_count, p->d_tw))));
         if (pe1) HIP_TRY(hipEventRecord(pe1[1], KS));
         HIP_TRY(hipEventRecord(p->ev_k1done[slot], KS));
@@ -1134,10 +1166,25 @@ static int check_fused_status(crsdr_plan *p)
         int w = 0;
         HIP_TRY(hipMemcpy(&w, p->d_sync + 2, sizeof(w), hipMemcpyDeviceToHost));
         if (w) {
-            (void)hipMemset(p->d_sync + 2, 0, 2 * sizeof(w));     // the flag and the work counter (its count is off after a failed launch)
+            // Roll back: every batch submitted since the last clean check may have folded garbage lags into the carried
+            // lag / mag / frac and EMA phase state.  Restore the snapshot taken before the first of them, re-arm the
+            // phase kernel's hand-over words, and keep this plan on the packed kernel from here on -- the caller
+            // resubmits those batches and gets what an undisturbed run would have given.
+            (void)hipStreamSynchronize(p->stream); (void)hipStreamSynchronize(p->aux); (void)hipStreamSynchronize(p->xs);
+            (void)hipMemset(p->d_sync, 0, 64);                    // flags and the work counter (its count is off after a failed launch)
             p->q_work_base = 0;
-            return fail(CRSDR_EHIP, "xcorr: %d workgroup(s) of the two-row kernel ran out of a bounded wait (results invalid; CRSDR_K1_VARIANT=packed avoids the kernel)", w);
+            if (p->snap_valid) {
+                (void)hipMemcpy(p->d_state, p->d_state_snap, p->state_bytes, hipMemcpyDeviceToDevice);
+                p->phase_cur = p->snap_phase_cur;
+            }
+            (void)hipMemset(p->d_corr, 0xFF, sizeof(long long) * 2 * (size_t)p->nrows * (size_t)p->max_batch);
+            p->chain_armed[0] = p->chain_armed[1] = p->max_batch;
+            p->snap_valid = false; p->k1_used = false; p->q_disabled = true; p->submitted = false;
+            return fail(CRSDR_EHIP, "xcorr: %d workgroup(s) of the two-row kernel ran out of a bounded wait; the batches submitted since the last "
+                                    "successful sync / fetch were rolled back (carried lag and phase state restored) -- resubmit them; this plan now "
+                                    "uses the packed kernel (CRSDR_K1_VARIANT=packed selects it from the start)", w);
         }
+        p->snap_valid = false; p->k1_used = false;               // clean: the next two-row launch takes a fresh snapshot
     }
     static const bool dbg = [] { const char *e = getenv("CRSDR_K2_DEBUG"); return e && atoi(e) != 0; }();
     if (!p->fused_used || !dbg) return CRSDR_OK;

@@ -214,7 +214,7 @@ __global__ __launch_bounds__(2 * QG, 1) void k_xcorr_lag14q(XcorrArgs a, const f
         // of the row loop and ~40 registers' worth of them live (spilled) across it
         int vt0 = tid, vt1 = tid + QG;
         asm volatile("" : "+v"(vt0), "+v"(vt1));
-        if (item >= nitems) break;
+        if ((unsigned)item >= (unsigned)nitems) break;     // also ends on a negative item (host / device counters out of step)
         const int t = item / row_count, row = a.row_begin + item % row_count;
         if (xcorr_skip(a, row, t, tid)) {
             q_barrier(sy, g, gen, 5);           // every wave of the group has read this item from next[g] before it is overwritten

@@ -54,11 +54,12 @@ cpacketize::sink_t cpacketize::sink;
 cpacketize::cpacketize() { objcount++; }                     // src/cpacketizer.cc:45-51
 cpacketize::~cpacketize() { objcount--; }
 
-bool cpacketize::refpadding = false;
+bool cpacketize::refpadding = true;    // the reference's message length is the default; false = the short form (no tail)
 size_t cpacketize::packetlength(uint32_t N, uint32_t L)
 {
-    // L = blocksize in int8 values.  The reference sizes the message 2*N*L data bytes (src/cpacketizer.cc:95, it counts
-    // complex samples twice) and sends all of it; with refpadding the same length goes on the wire, the tail zero
+    // L = blocksize in int8 values.  The reference sizes the message (16 + 4N) + 2*N*blocksize (src/cpacketizer.cc:91-96: it
+    // counts the int8 values twice) and sends all of it (:125); that length is what goes on the wire by default, the tail
+    // zero.  refpadding = false drops the tail (clients parse only the first N*blocksize data bytes, matlabclient/zmqsdr.c:121-143)
     const size_t data = (size_t)N * L * (refpadding ? 2 : 1);
     return noheader ? data : (16 + 4 * (size_t)N) + data;
 }

@@ -34,10 +34,10 @@ public:
     static std::string debugaddress;   // reference: "tcp://*:5557" (src/cpacketizer.cc:66); set before init()
     static sink_t sink;                // every sent packet also goes here (embedding / tests)
     static bool publishing();          // true when the ZMQ PUB sockets are bound
-    static bool refpadding;            // set before init(): messages carry the reference's 2x data length (zero tail), byte-length compatible
-    // Packet bytes for N channels of blocksize L: (16 + 4N) + N*L.  The reference allocates and sends 2*N*L data
-    // bytes (src/cpacketizer.cc:95), of which clients read N*L (matlabclient/zmqsdr.c:121-143); the zero tail is
-    // reproduced only with refpadding.
+    static bool refpadding;            // set before init(); default true: messages have the reference's length (below)
+    // Message bytes for N channels of blocksize L int8 values: the reference's (16 + 4N) + 2*N*L (src/cpacketizer.cc:91-96,
+    // sent whole at :125), of which clients read the first N*L data bytes (matlabclient/zmqsdr.c:121-143); the second
+    // N*L bytes are a zero tail here (unspecified memory in the reference).  refpadding = false: (16 + 4N) + N*L.
     static size_t packetlength(uint32_t N, uint32_t L);
 
     // -- per block, from the engine thread (src/ccoherent.cc:253,277-279,288; src/cpacketizer.cc:137-185)

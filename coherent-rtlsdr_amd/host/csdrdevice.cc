@@ -79,6 +79,7 @@ int8_t *csyntheticsdr::read()
         if (newdata.load() > 0) newdata--;
         cur = reinterpret_cast<int8_t *>(ring->getbufferptr());
         cur_rcnt = ring->get_rcnt();
+        held = true;                                         // the engine copies this slot outside the lock: the producer must not reuse it
         return cur;
     }
     cur = src->row(rowindex);
@@ -88,7 +89,7 @@ int8_t *csyntheticsdr::read()
 
 void csyntheticsdr::consume()
 {
-    if (ring) { std::lock_guard<std::mutex> lock(mtx); ring->consume(); }
+    if (ring) { std::lock_guard<std::mutex> lock(mtx); if (held) { held = false; ring->consume(); } }
 }
 
 void csyntheticsdr::asynch_threadf(csyntheticsdr *d)
@@ -105,9 +106,18 @@ void csyntheticsdr::asynch_threadf(csyntheticsdr *d)
         }
         {
             std::unique_lock<std::mutex> lock(d->mtx);
-            if (d->ring->backlog() >= d->ring->capacity()) {  // consumer too slow: the oldest block is lost (README.md:42)
-                d->ring->consume();
+            if (d->ring->backlog() >= d->ring->capacity()) {  // consumer too slow: a block is lost (README.md:42)
                 d->overruns++;
+                if (d->held) {
+                    // the oldest slot is the one the engine is copying right now (read() handed it out, consume() has
+                    // not come yet): overwriting it would tear that block under a valid readcnt -- the NEW block is
+                    // dropped instead (its readcnt is skipped, which is how clients see the gap)
+                    d->inc_readcnt();
+                    lock.unlock();
+                    if (d->pace_us) std::this_thread::sleep_for(std::chrono::microseconds(d->pace_us));
+                    continue;
+                }
+                d->ring->consume();                            // nobody holds it: the oldest unread block goes
                 if (d->newdata.load() > 0) d->newdata--;
             }
             uint8_t *w = d->ring->writeptr();

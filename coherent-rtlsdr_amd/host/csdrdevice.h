@@ -130,6 +130,7 @@ protected:
     std::atomic<int> newdata{0};
     std::atomic<bool> do_exit{false};
     uint32_t cur_rcnt = 0, produced = 0, overruns = 0;
+    bool held = false;          // guarded by mtx: read() handed the oldest ring slot to the engine, consume() has not returned it yet
     int pace_us = 0, max_blocks = 0;
     FILE *replay = nullptr;
     static void asynch_threadf(csyntheticsdr *d);
@@ -151,6 +152,8 @@ public:
     void stop();                                        // :36-42
     bool is_streaming_raw() const { return (bool)ring; } // rows are raw uint8 (offset binary) in streaming mode
     uint32_t get_overruns() const { return overruns; }
+    // streaming mode: the producer has made `total` blocks and none is left in the ring (read() would block for ever)
+    bool drained(uint32_t total) { std::lock_guard<std::mutex> lock(mtx); return ring && get_readcnt() >= total && ring->backlog() == 0; }
     int set_correction_f(float f) { correction = f; return 0; } // crtlsdr::set_correction_f src/crtlsdr.cc:167-170
     float get_correction_f() const { return correction; }
     void advance_resampler();                           // one block at the current correction: slip += p * L

@@ -545,7 +545,10 @@ def test_k1_variants_agree(tmp_path):
 def test_two_row_kernel_reports_a_wait_that_ran_out(tmp_path):
     # the two-row K1 (xcorr14q.hpp) bounds every wait for the LDS image / its group barriers.  With the bound forced to
     # zero polls (CRSDR_K1_QSPIN=0) waits do run out: the launch must terminate, the next sync / fetch must return an
-    # error (never silent garbage), and the plan must be usable again afterwards -- checked in a child process.
+    # error (never silent garbage), and the plan must be usable again afterwards: the failed batch is ROLLED BACK (carried
+    # lag / mag / frac and EMA phase state restored to what they were before it), the plan stays on the packed kernel,
+    # and resubmitting the batch -- then a locked batch that shifts by the carried lags -- gives bit for bit what a
+    # plan that never used the two-row kernel gives.  Checked in child processes (the variant is read once per process).
     import subprocess, sys, textwrap
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     code = textwrap.dedent('''
@@ -553,25 +556,45 @@ def test_two_row_kernel_reports_a_wait_that_ran_out(tmp_path):
         sys.path.insert(0, %r)
         pkg = importlib.import_module("coherent-rtlsdr_amd")
         b, synth = pkg.binding, pkg.synth
-        nsig, L, T = 300, 8192, 4
+        nsig, L, T1, T2 = 300, 8192, 4, 12
         params = synth.RowParams(nsig, L, 99, dmax=1000)
-        blocks = np.stack([synth.make_block(nsig, L, 99, t, params=params)[0] for t in range(T)])
-        plan = b.Plan(nsig + 1, 2 * L, b.MODE_DIGITAL, max_batch=T)
-        plan.submit(blocks, seq=0)
+        blocks = np.stack([synth.make_block(nsig, L, 99, t, params=params)[0] for t in range(T1 + T2 + T1)])
+        plan = b.Plan(nsig + 1, 2 * L, b.MODE_DIGITAL, max_batch=T2)
+        plan.submit(blocks[:T1], seq=0)                   # 1200 rows: the packed kernel under "auto" -- builds carried state
+        res = [plan.fetch(block=t) for t in range(T1)]
+        plan.submit(blocks[T1:T1 + T2], seq=T1)           # 3600 rows (>= 12 per CU): "auto" takes the two-row kernel
         try:
             plan.fetch(block=0)
             print("NOERROR")
         except b.CrsdrError as e:
             print("ERROR", e)
+            try:
+                plan.fetch(block=0)
+                print("STALE-FETCH-ALLOWED")
+            except b.CrsdrError:
+                pass                                      # nothing to fetch until the batch is resubmitted
+            plan.submit(blocks[T1:T1 + T2], seq=T1)       # resubmit: rolled back state + packed kernel
+        res += [plan.fetch(block=t) for t in range(T2)]
+        plan.submit(blocks[T1 + T2:], seq=T1 + T2, flags=b.REFNOISE_ENABLED | b.NO_LAG)     # locked: shifts by the carried lags
+        res += [plan.fetch(block=t) for t in range(T1)]
+        np.savez(sys.argv[1], lag=np.stack([r["lag"] for r in res]), mag=np.stack([r["mag"] for r in res]),
+                 phasor=np.stack([r["phasor"] for r in res]), packet=np.stack([r["packet"] for r in res]), d=params.d)
     ''') % root
-    env = dict(os.environ, CRSDR_K1_VARIANT="q", CRSDR_K1_QSPIN="0")
-    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
-    assert r.returncode == 0, r.stdout + r.stderr
-    assert "ERROR" in r.stdout and "bounded wait" in r.stdout, r.stdout + r.stderr
-    # the same launch with the normal bound is clean and exact
-    env = dict(os.environ, CRSDR_K1_VARIANT="q")
-    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
-    assert r.returncode == 0 and "NOERROR" in r.stdout, r.stdout + r.stderr
+    outs = {}
+    for name, env, expect in (("runout", {"CRSDR_K1_VARIANT": "auto", "CRSDR_K1_QSPIN": "0"}, "ERROR"),
+                              ("packed", {"CRSDR_K1_VARIANT": "packed"}, "NOERROR"),
+                              ("auto", {"CRSDR_K1_VARIANT": "auto"}, "NOERROR")):      # the same launches with the normal bound: clean
+        out = tmp_path / f"{name}.npz"
+        r = subprocess.run([sys.executable, "-c", code, str(out)], env=dict(os.environ, **env), capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stdout + r.stderr
+        assert expect in r.stdout and "STALE-FETCH-ALLOWED" not in r.stdout, r.stdout + r.stderr
+        if name == "runout":
+            assert "bounded wait" in r.stdout and "rolled back" in r.stdout, r.stdout
+        outs[name] = np.load(out)
+    for other in ("runout", "auto"):
+        for key in ("lag", "mag", "phasor", "packet"):
+            assert np.array_equal(outs["packed"][key].view(np.uint8), outs[other][key].view(np.uint8)), (other, key)
+    assert np.array_equal(outs["runout"]["lag"][-1, 1:], outs["runout"]["d"])
 
 
 def test_plan_lifecycle_does_not_leak_device_memory(b, synth):

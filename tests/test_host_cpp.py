@@ -46,6 +46,15 @@ def test_host_demo_builds(host_build):
     assert os.access(os.path.join(host_build, "coherent_demo"), os.X_OK)
 
 
+def test_block_ring_under_overrun_never_tears_a_block(host_build):
+    # the cbuffer ring with a producer faster than its reader (no GPU work): read() hands the oldest slot to the engine,
+    # which copies it OUTSIDE the lock; on overrun the producer must not reuse that slot (a torn block under a valid
+    # readcnt) nor make the reader's consume() drop a second, unread block.  ring_selftest checks every block it gets
+    # against the generator, that readcnts rise strictly and that consumed + dropped <= produced, with real drops.
+    r = subprocess.run([os.path.join(host_build, "ring_selftest"), "400"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "RING OK" in r.stdout, r.stdout + r.stderr
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("args", [["--cdsp", "--blocks", "12"], ["--faithful", "--blocks", "3"],
                                   ["--nsig", "21", "--L", "8192", "--blocks", "12"]])

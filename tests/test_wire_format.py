@@ -103,7 +103,7 @@ def test_packetizer_publishes_reference_wire_format(host_build, synth):
     params = synth.RowParams(nsig, L, 4242, dmax=L // 8)
     last = None
     for m in sub.msgs:
-        assert len(m) == 16 + 4 * (nsig + 1) + (nsig + 1) * 2 * L
+        assert len(m) == 16 + 4 * (nsig + 1) + 2 * (nsig + 1) * 2 * L      # the reference's packetlength, src/cpacketizer.cc:91-96
         gseq, c, rr, seqs, data, X = _parse_like_zmqsdr_c(m)
         assert (c, rr) == (nsig + 1, L)
         assert np.all(seqs == 1000 + gseq)                    # per-channel readcnt words
@@ -118,29 +118,32 @@ def test_packetizer_publishes_reference_wire_format(host_build, synth):
         assert ph.size == nsig + 1 and np.array_equal(ph.real, np.arange(nsig + 1))
 
 
-def test_reference_message_length_option(host_build, synth):
-    # the reference sends 16 + 4N + 2*N*B bytes per message (src/cpacketizer.cc:95,125: it doubles the data size), of
-    # which clients parse the first N*B data bytes (matlabclient/zmqsdr.c:121-143); cpacketize::refpadding reproduces
-    # that length with a zero tail for consumers that size their buffers by it
+@pytest.mark.parametrize("refpadding", [None, 1, 0])
+def test_on_wire_message_length_is_the_reference_formula(host_build, synth, refpadding):
+    # the reference sends packetlength = (16 + 4N) + 2*N*blocksize bytes per message (src/cpacketizer.cc:91-96,125: it
+    # doubles the data size), of which clients parse the first N*blocksize data bytes (matlabclient/zmqsdr.c:121-143).
+    # That length is the DEFAULT on the wire (zero tail); cpacketize::refpadding = false is the opt-in short form.
     z = _libzmq()
     nsig, L, blocks = 2, 128, 25
     addr, dbg = f"tcp://127.0.0.1:{_free_port()}", f"tcp://127.0.0.1:{_free_port()}"
     sub = Subscriber(z, addr, 1 << 20, 3)
     sub.start()
     time.sleep(0.2)
+    extra = [] if refpadding is None else ["--refpadding", str(refpadding)]
     r = subprocess.run([os.path.join(host_build, "packetizer_selftest"), "--nsig", str(nsig), "--L", str(L), "--blocks", str(blocks),
-                        "--zmq", addr, "--zmq-debug", dbg, "--refpadding", "1"], capture_output=True, text=True, timeout=60)
+                        "--zmq", addr, "--zmq-debug", dbg] + extra, capture_output=True, text=True, timeout=60)
     assert r.returncode == 0, r.stderr
     sub.join(10)
     assert len(sub.msgs) >= 3
     N, B = nsig + 1, 2 * L
+    ref_len = (16 + 4 * N) + 2 * N * B                         # packetlength() of the reference with its own argument names
     params = synth.RowParams(nsig, L, 4242, dmax=L // 8)
     for m in sub.msgs:
-        assert len(m) == 16 + 4 * N + 2 * N * B
+        assert len(m) == (ref_len if refpadding != 0 else ref_len - N * B)
         gseq, c, rr, seqs, data, _ = _parse_like_zmqsdr_c(m)
         rows, _ = synth.make_block(nsig, L, 4242, gseq, params=params)
         assert (c, rr) == (N, L) and np.array_equal(data, rows)
-        assert not any(m[16 + 4 * N + N * B:])                 # the tail is zero
+        assert not any(m[16 + 4 * N + N * B:])                 # the tail (if any) is zero
 
 
 @pytest.mark.gpu
