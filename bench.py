@@ -48,6 +48,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the locked-mode / large-working-set extras")
     ap.add_argument("--cpu-blocks", type=int, default=0, help="oracle blocks to time (0 = auto, ~10-20 s)")
+    ap.add_argument("--repeats", type=int, default=0, help="repeats of the timed region of exactly --steps steps, the median is reported "
+                    "(0 = auto: 5 when the region is shorter than ~50 ms, else 1)")
     return ap.parse_args()
 
 
@@ -91,9 +93,17 @@ def main():
     mode = b.MODE_DIGITAL if args.mode == "digital" else b.MODE_FAITHFUL
 
     # ---- synthetic resident input: nbuf distinct blocks, each rank fills row 0 + its slab ----------
-    T = max(1, min(args.batch if args.batch > 0 else 64, args.steps, 64))
-    if world > 1:
-        T = max(world, T // world * world)          # every rank assembles T/G blocks of each batch
+    # blocks per submit: the plan's maximum (64) when the timed region is long enough for >= 4 whole batches; for a short
+    # region (the driver's --steps 20) one GPU keeps the whole region in ONE launch set (its steady-state rate: the region is
+    # repeated and the median reported), several GPUs take T = a multiple of the world size with >= 4 whole batches where the
+    # step count allows (T = world at least: every rank roots T / world blocks of a batch), so that the exchange pipeline of the
+    # three ring-buffered sets is actually in flight inside the region.  A ragged last batch ships only its own bytes.
+    if args.batch > 0:
+        T = max(1, min(args.batch, 64))
+    elif world == 1:
+        T = max(1, min(64, args.steps))
+    else:
+        T = max(world, min(64, (args.steps // 4) // world * world))
     nbuf = max(2 * T if world > 1 else T, (args.nbuf // T) * T)   # whole batches, contiguous in HBM
     seed = synth.config_seed(4)
     params = synth.RowParams(nsig, L, seed)
@@ -108,27 +118,29 @@ def main():
     stream = torch.cuda.current_stream()
     plan.set_stream(stream.cuda_stream)
     # NSETS ring-buffered output sets (the exchange of batch i runs under the compute of batch i+1); the matrix
-    # of every packet is 16-byte aligned.  One GPU: T packets per set.  Several GPUs: per set one dense slab
-    # buffer [T][rows_per_rank][B] (the all-to-all's send side), one receive buffer of the same size and the
-    # Tg = T/G packets this rank assembles.
+    # of every packet is 16-byte aligned.  One GPU: T packets per set.  Several GPUs: per set one slot buffer
+    # [T][slot_stride] (rows + the 20 B/row {lag, mag, frac, phasor} tail of the rank's slab: the all-to-all's send side),
+    # one receive buffer [G][Tg][slot_stride], the Tg = ceil(T/G) packets this rank assembles and their scalars blocks.
     NSETS = 3 if world > 1 else 2
-    Tg = T // world
+    Tg = -(-T // world)
     pstride = (plan.packet_bytes + 255) // 256 * 256
     packets = [torch.zeros(pstride * Tg + 64, dtype=torch.uint8, device=dev) for _ in range(NSETS)]
     pk_off = [(-(p.data_ptr() + plan.matrix_offset)) % 16 for p in packets]
     pk_view = [[p[o + t * pstride: o + t * pstride + plan.packet_bytes] for t in range(Tg)] for p, o in zip(packets, pk_off)]
     flags = b.REFNOISE_ENABLED | b.INPUT_READY
-    slab_bytes = slab.row_count * B
     if world > 1:
-        send = [torch.zeros(T * slab_bytes, dtype=torch.uint8, device=dev) for _ in range(NSETS)]
-        recv = [torch.zeros(T * slab_bytes, dtype=torch.uint8, device=dev) for _ in range(NSETS)]
+        geo = b.exchange_geometry(nrows, B, world)
+        slot, toff, sstride = geo["slot_stride"], geo["tail_offset"], geo["scalars_stride"]
+        send = [torch.zeros(T * slot, dtype=torch.uint8, device=dev) for _ in range(NSETS)]
+        recv = [torch.zeros(world * Tg * slot, dtype=torch.uint8, device=dev) for _ in range(NSETS)]
+        scal = [torch.zeros(Tg * sstride, dtype=torch.uint8, device=dev) for _ in range(NSETS)]
         xstream = torch.cuda.Stream(device=dev)       # waits for the exchange, then assembles: never blocks the compute stream
         done = [None] * NSETS                          # event: set k's exchange + assembly finished
-        mine = sharding.rooted_blocks(T, world, rank)
+    xchg = {"c": None}                                 # crsdr_exchange (RCCL under the C ABI) when the C transport is selected
 
     def run_batch(ib, nb, fl=flags):
-        """blocks [ib*T, ib*T + nb) of the stream: one submit; with several GPUs then ONE all-to-all of the batch's
-        slabs (rank q assembles blocks [q*T/G, (q+1)*T/G) of every batch) and the assembly on a side stream"""
+        """blocks [ib*T, ib*T + nb) of the stream: one submit; with several GPUs then ONE exchange of the batch's slots
+        (rank q assembles the q-th run of ceil(nb/G) blocks, rows AND per-row scalars) and the assembly on a side stream"""
         k = ib % NSETS
         first_buf = (ib * T) % nbuf
         if world == 1:
@@ -137,20 +149,35 @@ def main():
             return
         if done[k] is not None:
             stream.wait_event(done[k])               # set k is free again: its exchange and assembly are complete
+        mine = sharding.rooted_range(nb, world, rank)
         plan.bind_packet(pk_view[k][0].data_ptr(), pstride)
-        plan.bind_slab(send[k].data_ptr(), slab_bytes, mine.start, len(mine))
+        plan.bind_slab_ex(send[k].data_ptr(), slot, mine.start, len(mine), toff)
         plan.submit(d_in[first_buf].data_ptr(), seq=ib * T, flags=fl, nblocks=nb, block_stride=block_bytes)
         if rehearsal:
             plan.sync()
-            h_send, h_recv = send[k].cpu(), torch.empty(T * slab_bytes, dtype=torch.uint8)
-            sharding.exchange_batch(h_recv, h_send, async_op=False)
+            h_send, h_recv = send[k].cpu(), torch.empty(world * Tg * slot, dtype=torch.uint8)
+            sharding.exchange_slots(h_recv, h_send, nb, slot, async_op=False)
             recv[k].copy_(h_recv)
-            b.assemble_slabs(pk_view[k][0].data_ptr(), pstride, nrows, B, recv[k].data_ptr(), world, Tg, stream.cuda_stream)
+            if len(mine):
+                b.assemble_slots(pk_view[k][0].data_ptr(), pstride, scal[k].data_ptr(), sstride, nrows, B, recv[k].data_ptr(), world, len(mine), slot, toff,
+                                 stream=stream.cuda_stream)
             return
-        work = sharding.exchange_batch(recv[k], send[k], async_op=True)     # RCCL stream: ordered after the submit above
+        if xchg["c"] is not None:
+            # the same exchange under the C ABI: grouped ncclSend / ncclRecv + assembly, all enqueued on the side stream
+            ready = torch.cuda.Event()
+            ready.record(stream)
+            xstream.wait_event(ready)
+            xchg["c"].batch(b.XCHG_STAGED, send[k].data_ptr(), recv[k].data_ptr(), nb, pk_view[k][0].data_ptr(), pstride, scal[k].data_ptr(), sstride,
+                            nrows, B, xstream.cuda_stream)
+            done[k] = torch.cuda.Event()
+            done[k].record(xstream)
+            return
+        work = sharding.exchange_slots(recv[k], send[k], nb, slot, async_op=True)     # RCCL stream: ordered after the submit above
         with torch.cuda.stream(xstream):
             work.wait()                              # stream-level: xstream waits for the all-to-all
-            b.assemble_slabs(pk_view[k][0].data_ptr(), pstride, nrows, B, recv[k].data_ptr(), world, Tg, xstream.cuda_stream)
+            if len(mine):
+                b.assemble_slots(pk_view[k][0].data_ptr(), pstride, scal[k].data_ptr(), sstride, nrows, B, recv[k].data_ptr(), world, len(mine), slot, toff,
+                                 stream=xstream.cuda_stream)
             done[k] = torch.cuda.Event()
             done[k].record(xstream)
 
@@ -187,33 +214,41 @@ def main():
     # between each rank pair -- do that here, on the still-empty buffers, so that connection set-up cannot land
     # inside the timed region whatever the warm-up length is
     if world > 1 and not rehearsal:
-        sharding.exchange_batch(recv[NSETS - 1], send[NSETS - 1], async_op=False)
+        sharding.exchange_slots(recv[NSETS - 1], send[NSETS - 1], T, slot, async_op=False)
         torch.cuda.synchronize()
         dist.barrier()
 
     # ---- warm-up, then the timed region with per-kernel HIP events on the launch streams ----------
     run_steps(args.warmup)
     fence()
-    # timed region: hipEvent pairs around the dominant kernel (K1) only -- every pair costs stream time
-    plan.enable_profiling(min(max(args.steps, 1), 1024), 1 << b.KERNEL_XCORR_LAG)
-    dt = timed(args.steps)
-    # checked right here, before later (untimed) runs reuse the packet sets -- the last full batch: every packet this rank assembled must hold a slab from every rank (row 0 of each
-    # slab is non-zero int8 data with overwhelming probability) under the header of the right block
-    assembled_ok = True
+    # timed region: hipEvent pairs around the dominant kernel (K1) only -- every pair costs stream time.  The region of
+    # exactly --steps steps is repeated and the MEDIAN reported: a 1 ms region between two device-wide fences is noise-prone
+    nbatch = -(-args.steps // T)
+    est_ms = args.steps * 0.06 / world
+    repeats = args.repeats if args.repeats > 0 else (5 if est_ms < 50 else 1)
+    plan.enable_profiling(min(max(nbatch * repeats, 1), 4096), 1 << b.KERNEL_XCORR_LAG)
+    dts = [timed(args.steps) for _ in range(repeats)]
+    dt = float(np.median(dts))
+    # checked right here, before later (untimed) runs reuse the packet sets: the last full batch -- every packet this rank
+    # assembled must hold every rank's rows under the header of the right block, and its scalars block every rank's lags
+    assembled_ok = scalars_ok = True
     if world > 1:
         torch.cuda.synchronize()
         nfull = args.steps // T
         if nfull:
             ib = nfull - 1
+            mine = sharding.rooted_range(T, world, rank)
             for j, t_ in enumerate(mine):
                 pkv = pk_view[ib % NSETS][j]
                 m = sharding.matrix_view(pkv, nrows, B)
                 for r in range(world):
                     assembled_ok &= bool(m[1 + r * slab.rows_per_rank].ne(0).any().item())
                 assembled_ok &= int(pkv[:4].cpu().numpy().view(np.uint32)[0]) == ib * T + t_
-        flag = torch.tensor([1 if assembled_ok else 0], device="cpu" if rehearsal else dev, dtype=torch.int32)
+                sc = b.parse_scalars(scal[ib % NSETS][j * sstride: (j + 1) * sstride].cpu().numpy(), nrows)
+                scalars_ok &= bool(np.array_equal(sc["lag"][1:], params.d)) and bool(np.all(np.abs(sc["phasor"][1:]) > 0.2))
+        flag = torch.tensor([1 if assembled_ok else 0, 1 if scalars_ok else 0], device="cpu" if rehearsal else dev, dtype=torch.int32)
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-        assembled_ok = bool(flag.item())
+        assembled_ok, scalars_ok = bool(flag[0].item()), bool(flag[1].item())
 
     host_ms_per_batch = 1e3 * host_issue["s"] / max(1, -(-args.steps // T))
     k_ms = {"xcorr_lag": plan.kernel_times_ms(b.KERNEL_XCORR_LAG)}
@@ -224,8 +259,21 @@ def main():
     for name, k in (("ref_spectrum", b.KERNEL_REF_SPECTRUM), ("phase_dot", b.KERNEL_PHASE_DOT), ("align_quant", b.KERNEL_ALIGN_QUANT)):
         k_ms[name] = plan.kernel_times_ms(k)
     plan.enable_profiling(0)
-    full_batches = args.steps // T      # launches that carried exactly T blocks come first
+    full_batches = args.steps // T      # launches per repeat that carried exactly T blocks
     blocks_per_s = args.steps / dt
+    # K0 exposed: one cold batch (nothing in flight before it) with whole-submit events: what the batch takes beyond its K1 and
+    # phase kernel is the reference-spectrum kernel it had to wait for plus launch gaps; in the steady state K0 of batch b+1
+    # runs on the aux stream under batch b and the region's own "unhidden" remainder (below) is what is left of it
+    cold = None
+    if world == 1:
+        plan.enable_profiling(4, 0xF | (1 << 31))
+        fence()
+        run_batch(0, T)
+        fence()
+        tot = plan.last_elapsed_ms()
+        parts = [plan.kernel_times_ms(k) for k in (b.KERNEL_XCORR_LAG, b.KERNEL_PHASE_DOT, b.KERNEL_ALIGN_QUANT)]
+        cold = {"submit_ms": tot, "k0_exposed_ms": max(0.0, tot - sum(float(x[-1]) for x in parts if len(x)))}
+        plan.enable_profiling(0)
 
     # parity spot-check of the timed path against the injected delays (every rank, its slab)
     out = plan.fetch(want_packet=False)
@@ -235,7 +283,8 @@ def main():
     result = None
     if rank == 0:
         A_block = nrows * B                                   # algorithmic bytes per block
-        k1s = k_ms["xcorr_lag"][:full_batches] if full_batches else k_ms["xcorr_lag"]
+        k1_all = k_ms["xcorr_lag"]
+        k1s = [x for i, x in enumerate(k1_all) if (i % nbatch) < full_batches] if full_batches else k1_all      # launches that carried T blocks
         k1 = float(np.mean(k1s)) if len(k1s) else float("nan")
         tb = T if full_batches else args.steps
         k1_bytes = tb * slab.row_count * B                    # int8 bytes one K1 launch consumes (tb blocks)
@@ -244,14 +293,17 @@ def main():
         result = {
             "metric": f"aligned IQ blocks/s ({nsig} ch x {L})", "value": blocks_per_s, "unit": "blocks/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
+            "repeats": repeats, "value_spread": [args.steps / max(dts), args.steps / min(dts)],     # the region is timed `repeats` times: value = median
+            "batches_timed": {"per_repeat": nbatch, "whole": full_batches, "ragged_blocks": args.steps - full_batches * T, "blocks_per_batch": T},
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{'cfg5' if args.cfg5 else {21: 'cfg2', 256: 'cfg3', 1024: 'cfg4'}.get(nsig, 'custom') if L == 8192 else 'custom'}: 1 ref + {nsig} signal rows x {L} int8 IQ samples per block, track cadence "
                                    f"(FFT xcorr every block), {args.mode} mode, inputs resident in HBM, "
                                    f"{nbuf} rotating input blocks, {T} blocks per submit",
                        "rows": nrows, "L": L, "fft_len": B, "mode": args.mode, "batch": T,
-                       "parallelism": f"rows sharded x{world}, ref replicated, rotating-root int8 gather: one RCCL all-to-all per {T}-block batch + local assembly, overlapped with the next batch" if world > 1 else "single GPU"},
+                       "parallelism": f"rows sharded x{world}, ref replicated, rotating-root gather of int8 rows + 20 B/row {{lag, mag, frac, phasor}}: one RCCL all-to-all per {T}-block batch + local assembly, overlapped with the next batch" if world > 1 else "single GPU"},
             "roofline": {"bound": "hbm", "kernel": "k_xcorr_lag", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": _committed_traffic("k_xcorr_lag", tb),
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": _committed_traffic("k_xcorr_lag", tb)[0],
+                         "traffic_source": _committed_traffic("k_xcorr_lag", tb)[1],
                          "algorithmic_bytes_per_launch": k1_bytes, "avg_launch_ms": k1,
                          "valu_frac": (tb * slab.row_count * flop_row / (k1 * 1e-3)) / (FP32_VALU_PEAK_TF * 1e12),
                          "blocks_per_launch": tb,
@@ -261,7 +313,9 @@ def main():
                            "hbm_read_frac": A_block * blocks_per_s / (world * HBM_PEAK_GBS * 1e9)},
             "kernel_ms": {k: (k1 if k == "xcorr_lag" else float(np.mean(v)) if len(v) else None) for k, v in k_ms.items()},   # per launch of `batch` blocks
             "host_issue_ms_per_batch": host_ms_per_batch,
-            "lags_exact": lags_ok, "matrix_assembled": assembled_ok if world > 1 else None,
+            "k0": {"launch_ms": float(np.mean(k_ms["ref_spectrum"])) if len(k_ms["ref_spectrum"]) else None, "cold_batch": cold,
+                   "note": "K0 runs on the aux stream under the previous batch; cold_batch = one batch with nothing in flight before it"},
+            "lags_exact": lags_ok, "matrix_assembled": assembled_ok if world > 1 else None, "scalars_assembled": scalars_ok if world > 1 else None,
             "env": _env(torch, dev, b, local_rank),
         }
 
@@ -288,7 +342,8 @@ def main():
                                              "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": rd / (k2m * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                              "read_plus_write_GBs": 2 * rd / (k2m * 1e-3) / 1e9, "avg_launch_ms": k2m,
                                              "phase_dot_avg_launch_ms": k2am, "blocks_per_launch": T,
-                                             "traffic": _committed_traffic("k_align_quant" if k2am is not None else "k_align_fused", T)},
+                                             "traffic": _committed_traffic("k_align_quant" if k2am is not None else "k_align_fused", T)[0],
+                                             "traffic_source": _committed_traffic("k_align_quant" if k2am is not None else "k_align_fused", T)[1]},
                                 "hbm_read_frac": (nrows * B) * (n_l / dt_l) / (world * HBM_PEAK_GBS * 1e9)}
 
     # ---- extra: downstream covariance of one aligned matrix on the matrix cores ----------
@@ -331,6 +386,53 @@ def main():
     elif rank == 0:
         result["cpu_baseline"] = None
 
+    # ---- extra, several GPUs: the same exchange through the C ABI (crsdr_exchange_*: grouped ncclSend / ncclRecv issued by
+    # libcrsdr.so itself, no Python collective in the loop).  `value` above was timed with torch.distributed's all-to-all;
+    # this leg re-times the same steps with the C transport.  It has never run on more than one GPU before the driver's
+    # node (RCCL refuses two ranks on one device), so it runs LAST and under a watchdog: if it does not finish, every rank
+    # reports what it has and leaves -- the figures above are not at risk.  CRSDR_BENCH_C_EXCHANGE=0 skips it.
+    if world > 1 and not rehearsal and os.environ.get("CRSDR_BENCH_C_EXCHANGE", "1") != "0":
+        import threading
+
+        def bail():
+            if rank == 0:
+                result["c_exchange"] = {"status": "timeout: the C-ABI RCCL leg did not finish within 90 s; figures above are from the torch.distributed transport"}
+                print(json.dumps(result), flush=True)
+            os._exit(0)
+
+        wd = threading.Timer(90.0, bail)
+        wd.daemon = True
+        wd.start()
+        try:
+            ids = [b.exchange_unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(ids, src=0)
+            xchg["c"] = b.Exchange(ids[0], world, rank, local_rank)
+            run_steps(max(args.warmup, 2 * T))
+            fence()
+            dts_c = [timed(args.steps) for _ in range(repeats)]
+            dt_c = float(np.median(dts_c))
+            torch.cuda.synchronize()
+            ok = True
+            nfull = args.steps // T
+            if nfull:
+                ib = nfull - 1
+                for j, t_ in enumerate(sharding.rooted_range(T, world, rank)):
+                    sc = b.parse_scalars(scal[ib % NSETS][j * sstride: (j + 1) * sstride].cpu().numpy(), nrows)
+                    ok &= bool(np.array_equal(sc["lag"][1:], params.d))
+                    ok &= int(pk_view[ib % NSETS][j][:4].cpu().numpy().view(np.uint32)[0]) == ib * T + t_
+            flag = torch.tensor([1 if ok else 0], device=dev, dtype=torch.int32)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if rank == 0:
+                result["c_exchange"] = {"status": "ok", "blocks_per_s": args.steps / dt_c, "ms_per_step": 1e3 * dt_c / args.steps,
+                                        "assembled": bool(flag.item()), "transport": "crsdr_exchange_batch (staged): grouped ncclSend/ncclRecv + crsdr assembly, one side stream"}
+        except Exception as e:                       # a failure here must not take the measured figures with it
+            if rank == 0:
+                result["c_exchange"] = {"status": f"error: {e}"}
+        wd.cancel()
+        xc, xchg["c"] = xchg["c"], None
+        if xc is not None:
+            xc.close()
+
     if rank == 0:
         print(json.dumps(result))
     plan.close()
@@ -370,22 +472,25 @@ def _env(torch, dev, b, local_rank):
 
 
 def _committed_traffic(kernel, blocks_per_launch=None):
-    """HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/*traffic*.json), else null.  The passes
-    record how many blocks their launches carried; the figure is scaled to this run's blocks per launch (the kernels
-    move the same bytes per block whatever the batch length)."""
+    """(HBM bytes per launch, where the figure comes from) from the committed rocprofv3 --pmc passes
+    (profiles/*traffic*.json), else (None, None).  NOT measured in this run: the passes record how many blocks their
+    launches carried and the figure is scaled to this run's blocks per launch (the kernels move the same bytes per block
+    whatever the batch length); the source string names the file and both block counts."""
     import glob
-    best = None
+    best, src = None, None
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*traffic*.json"))):
         try:
             d = json.load(open(f))
             if kernel in d:
                 e = d[kernel]
                 best = e["bytes_per_launch"] if isinstance(e, dict) else e
+                src = f"{os.path.relpath(f, ROOT)} (committed rocprofv3 --pmc pass, not this run)"
                 if isinstance(e, dict) and blocks_per_launch and e.get("blocks_per_launch"):
                     best = int(round(best * blocks_per_launch / e["blocks_per_launch"]))
+                    src += f": {e['bytes_per_launch']} B per {e['blocks_per_launch']}-block launch, scaled to {blocks_per_launch} blocks"
         except Exception:
             pass
-    return best
+    return best, src
 
 
 def _cpu_baseline(args, rows, nrows, B, mode):
@@ -394,7 +499,8 @@ def _cpu_baseline(args, rows, nrows, B, mode):
     all-cores row.  Bounded sample of the same workload (~10-20 s)."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import oracle_py as O
-    eng = O.Engine(nrows, B, mode)
+    refl = O.lib_refflags()                 # the reference's compiler flags (-O3, no -march: CMakeLists.txt:10); the -mavx2 build is timed beside it
+    eng = O.Engine(nrows, B, mode, cdll=refl)
     t0 = time.perf_counter()
     eng.block(rows, want_packet=True)
     one = time.perf_counter() - t0
@@ -407,12 +513,20 @@ def _cpu_baseline(args, rows, nrows, B, mode):
     nthreads = max(1, min(ncpu, 64))
     nbm = max(2, min(64, int(6.0 / max(one / nthreads, 1e-3))))
     t0 = time.perf_counter()
+    engm = O.Engine(nrows, B, mode, cdll=refl)
     for i in range(nbm):
-        eng.block(rows, seq=i, nthreads=nthreads)
+        engm.block(rows, seq=i, nthreads=nthreads)
     dtm = time.perf_counter() - t0
     # the reference as shipped: at most nfft = 8 rows (ref + 7) are cross-correlated per block (src/main.cc:165,
     # src/ccoherent.cc:124); every row still goes through the phase path
-    eng8 = O.Engine(nrows, B, mode, nfft_cap=8)
+    engx = O.Engine(nrows, B, mode)        # same sources, -O3 -mavx2 (the checker's build)
+    engx.block(rows)
+    nbx = max(1, nb // 2)
+    t0 = time.perf_counter()
+    for i in range(nbx):
+        engx.block(rows, seq=i)
+    dtx = time.perf_counter() - t0
+    eng8 = O.Engine(nrows, B, mode, nfft_cap=8, cdll=refl)
     eng8.block(rows)
     nb8 = max(2, min(16, int(4.0 / max(one / 8, 1e-3))))
     t0 = time.perf_counter()
@@ -425,8 +539,9 @@ def _cpu_baseline(args, rows, nrows, B, mode):
     return {"value": nb / dt1, "unit": "blocks/s", "cores": 1, "kind": "port", "host_has_fftw3f_volk": genuine,
             "ref8": {"value": nb8 / dt8, "cores": 1, "sample": f"{nb8} blocks with the reference's nfft = 8 queue cap (7 of the {nrows - 1} "
                                                                f"signal rows get a lag per block, all get the phase path)"},
-            "sample": f"{nb} blocks of the same {nrows} x {B // 2} workload, oracle/coherent_oracle.c -O3 -mavx2, 1 thread "
+            "sample": f"{nb} blocks of the same {nrows} x {B // 2} workload, oracle/coherent_oracle.c built with the reference's flags (-O3, no -march), 1 thread "
                       f"(the reference runs one ccoherent thread); reference itself unbuildable here (VOLK/FFTW absent)",
+            "flags": "-O3 (CMakeLists.txt:10)", "avx2": {"value": nbx / dtx, "cores": 1, "sample": f"{nbx} blocks, same sources built -O3 -mavx2"},
             "allcores": {"value": nbm / dtm, "cores": nthreads, "sample": f"{nbm} blocks, rows split over {nthreads} pthreads"}}
 
 

@@ -31,7 +31,11 @@ ABI_SYMBOLS = [
     "crsdr_plan_submit_batch", "crsdr_plan_fetch_block", "crsdr_plan_packet_stride", "crsdr_covariance",
     "crsdr_noisesubspace", "crsdr_pmusic2d", "crsdr_plan_bind_slab", "crsdr_assemble_slabs",
     "crsdr_device_info", "crsdr_host_alloc", "crsdr_host_free",
+    "crsdr_plan_bind_slab_ex", "crsdr_exchange_geometry", "crsdr_exchange_rooted_blocks", "crsdr_assemble_slots",
+    "crsdr_exchange_unique_id", "crsdr_exchange_create", "crsdr_exchange_destroy", "crsdr_exchange_batch", "crsdr_exchange_schedule",
 ]
+XCHG_STAGED, XCHG_INPLACE = 0, 1
+EXCHANGE_ID_BYTES = 128
 KERNEL_REF_SPECTRUM, KERNEL_XCORR_LAG, KERNEL_PHASE_DOT, KERNEL_ALIGN_QUANT = 0, 1, 2, 3
 
 
@@ -49,6 +53,12 @@ def build(force: bool = False) -> str:
     if stale:
         subprocess.run(["make", "-C", csrc], check=True)
     return _SO
+
+
+class XOp(C.Structure):
+    """crsdr_xop: one point-to-point operation of an exchange batch (crsdr_exchange_schedule)."""
+    _fields_ = [("peer", C.c_int32), ("is_recv", C.c_int32), ("buffer", C.c_int32), ("block", C.c_int32),
+                ("offset", C.c_uint64), ("bytes", C.c_uint64)]
 
 
 class PlanDesc(C.Structure):
@@ -109,6 +119,16 @@ def lib():
     L.crsdr_plan_bind_slab.argtypes = [vp, vp, C.c_size_t, C.c_int, C.c_int]
     L.crsdr_assemble_slabs.argtypes = [vp, C.c_size_t, C.c_int, C.c_int, vp, C.c_int, C.c_int, vp]
     L.crsdr_plan_submit_batch.argtypes = [vp, vp, C.c_int, C.c_int, C.c_size_t, u32p, u8p, C.c_uint32, C.c_uint32]
+    szp = C.POINTER(C.c_size_t)
+    L.crsdr_plan_bind_slab_ex.argtypes = [vp, vp, C.c_size_t, C.c_int, C.c_int, C.c_size_t]
+    L.crsdr_exchange_geometry.argtypes = [C.c_int, C.c_int, C.c_int, szp, szp, szp]
+    L.crsdr_exchange_rooted_blocks.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    L.crsdr_assemble_slots.argtypes = [vp, C.c_size_t, vp, C.c_size_t, C.c_int, C.c_int, vp, C.c_int, C.c_int, C.c_size_t, C.c_size_t, C.c_int, vp, vp]
+    L.crsdr_exchange_unique_id.argtypes = [vp]
+    L.crsdr_exchange_create.argtypes = [C.POINTER(vp), vp, C.c_int, C.c_int, C.c_int]
+    L.crsdr_exchange_destroy.argtypes = [vp]
+    L.crsdr_exchange_batch.argtypes = [vp, C.c_int, vp, vp, C.c_int, vp, C.c_size_t, vp, C.c_size_t, C.c_int, C.c_int, vp]
+    L.crsdr_exchange_schedule.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_size_t, C.POINTER(XOp), C.c_int, C.POINTER(C.c_int)]
     L.crsdr_plan_fetch_block.argtypes = [vp, C.c_int, i32p, f32p, f32p, f32p, i8p]
     L.crsdr_plan_packet_stride.argtypes = [vp]
     L.crsdr_plan_packet_stride.restype = C.c_size_t
@@ -283,6 +303,79 @@ def assemble_slabs(packets_ptr: int, packet_stride: int, nrows: int, B: int, rec
                                       int(nsrc), int(nblocks), C.c_void_p(stream or 0)))
 
 
+# ---- exchange slots + the RCCL exchange --------------------------------------------------
+
+def exchange_geometry(nrows: int, B: int, nranks: int) -> dict:
+    """crsdr_exchange_geometry: slot_stride / tail_offset of a rank's send slots and the stride of an assembled scalars block."""
+    a, t, s = C.c_size_t(0), C.c_size_t(0), C.c_size_t(0)
+    _check(lib().crsdr_exchange_geometry(int(nrows), int(B), int(nranks), C.byref(a), C.byref(t), C.byref(s)))
+    return {"slot_stride": a.value, "tail_offset": t.value, "scalars_stride": s.value, "per": (nrows - 1) // nranks}
+
+
+def rooted_blocks(nblocks: int, nranks: int, rank: int) -> range:
+    """crsdr_exchange_rooted_blocks: the blocks of a batch of nblocks that `rank` assembles."""
+    f, c = C.c_int(0), C.c_int(0)
+    _check(lib().crsdr_exchange_rooted_blocks(int(nblocks), int(nranks), int(rank), C.byref(f), C.byref(c)))
+    return range(f.value, f.value + c.value)
+
+
+def assemble_slots(packets_ptr, packet_stride, scalars_ptr, scalars_stride, nrows, B, recv_ptr, nsrc, nblocks, slot_stride, tail_offset,
+                   self_rank=-1, self_ptr=None, stream=None):
+    """crsdr_assemble_slots: received slots [nsrc][nblocks][slot_stride] -> matrix rows of nblocks packets + their scalars blocks."""
+    _check(lib().crsdr_assemble_slots(C.c_void_p(int(packets_ptr)), int(packet_stride), C.c_void_p(int(scalars_ptr or 0)), int(scalars_stride),
+                                      int(nrows), int(B), C.c_void_p(int(recv_ptr or 0)), int(nsrc), int(nblocks), int(slot_stride), int(tail_offset),
+                                      int(self_rank), C.c_void_p(int(self_ptr or 0)), C.c_void_p(stream or 0)))
+
+
+def parse_scalars(block: np.ndarray, nrows: int) -> dict:
+    """One assembled scalars block (bytes) -> {lag, mag, frac, phasor} like Plan.fetch."""
+    raw = np.ascontiguousarray(block).view(np.uint8)
+    n = nrows
+    return dict(lag=raw[:4 * n].view(np.int32).copy(), mag=raw[4 * n:8 * n].view(np.float32).copy(),
+                frac=raw[8 * n:12 * n].view(np.float32).copy(), phasor=raw[12 * n:20 * n].view(np.complex64).copy())
+
+
+def exchange_schedule(nranks, rank, nblocks, mode, nrows, B, packet_stride=0):
+    """crsdr_exchange_schedule: the point-to-point operations of one batch for `rank`, in issue order (list of dicts)."""
+    n = C.c_int(0)
+    _check(lib().crsdr_exchange_schedule(int(nranks), int(rank), int(nblocks), int(mode), int(nrows), int(B), int(packet_stride), None, 0, C.byref(n)))
+    ops = (XOp * max(1, n.value))()
+    _check(lib().crsdr_exchange_schedule(int(nranks), int(rank), int(nblocks), int(mode), int(nrows), int(B), int(packet_stride), ops, n.value, C.byref(n)))
+    return [dict(peer=o.peer, is_recv=bool(o.is_recv), buffer=o.buffer, block=o.block, offset=int(o.offset), bytes=int(o.bytes)) for o in ops[: n.value]]
+
+
+def exchange_unique_id() -> bytes:
+    buf = C.create_string_buffer(EXCHANGE_ID_BYTES)
+    _check(lib().crsdr_exchange_unique_id(buf))
+    return buf.raw
+
+
+class Exchange:
+    """crsdr_exchange: the slot exchange over RCCL under the C ABI (one per rank; every rank passes rank 0's unique id)."""
+
+    def __init__(self, unique_id: bytes, nranks: int, rank: int, device: int = 0):
+        h = C.c_void_p()
+        idbuf = C.create_string_buffer(bytes(unique_id), EXCHANGE_ID_BYTES)
+        _check(lib().crsdr_exchange_create(C.byref(h), idbuf, int(nranks), int(rank), int(device)))
+        self._h, self.nranks, self.rank = h, nranks, rank
+
+    def batch(self, mode, send_ptr, recv_ptr, nblocks, packets_ptr, packet_stride, scalars_ptr, scalars_stride, nrows, B, stream=None):
+        _check(lib().crsdr_exchange_batch(self._h, int(mode), C.c_void_p(int(send_ptr)), C.c_void_p(int(recv_ptr or 0)), int(nblocks),
+                                          C.c_void_p(int(packets_ptr)), int(packet_stride), C.c_void_p(int(scalars_ptr or 0)), int(scalars_stride),
+                                          int(nrows), int(B), C.c_void_p(stream or 0)))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().crsdr_exchange_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 # ---- batched plan ---------------------------------------------------------------------------------
 
 class Plan:
@@ -357,6 +450,10 @@ class Plan:
     def bind_slab(self, device_ptr: int | None, slab_stride: int = 0, hdr_first: int = 0, hdr_count: int = 0):
         """Slab output for sharded plans (crsdr_plan_bind_slab); None returns to packet output."""
         _check(lib().crsdr_plan_bind_slab(self._h, C.c_void_p(device_ptr or 0), int(slab_stride), int(hdr_first), int(hdr_count)))
+
+    def bind_slab_ex(self, device_ptr: int | None, slab_stride: int = 0, hdr_first: int = 0, hdr_count: int = 0, tail_offset: int = 0):
+        """crsdr_plan_bind_slab_ex: slab output with the per-row {lag, mag, frac, phasor} tail behind the rows of every slot."""
+        _check(lib().crsdr_plan_bind_slab_ex(self._h, C.c_void_p(device_ptr or 0), int(slab_stride), int(hdr_first), int(hdr_count), int(tail_offset)))
 
     @property
     def packet_stride(self) -> int:

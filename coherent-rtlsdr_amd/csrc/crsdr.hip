@@ -610,7 +610,7 @@ struct crsdr_plan {
     uint8_t *d_packet_alloc = nullptr; // own packet allocation (front padding for alignment)
     int8_t *d_packet_own = nullptr, *d_packet = nullptr;
     int8_t *d_slab = nullptr;          // slab output mode (crsdr_plan_bind_slab), caller-owned
-    size_t slab_stride = 0;
+    size_t slab_stride = 0, tail_offset = 0;   // tail_offset: crsdr_plan_bind_slab_ex -- per-row scalars after the rows of every slot
     int hdr_first = 0, hdr_count = 0;
     uint32_t *d_readcnt = nullptr;     // [T][nrows]
     uint8_t *d_mask = nullptr;
@@ -852,6 +852,7 @@ extern "C" size_t crsdr_plan_matrix_offset(const crsdr_plan *p) { return p ? p->
 extern "C" int crsdr_plan_bind_slab(crsdr_plan *p, void *device_slab, size_t slab_stride, int hdr_first, int hdr_count)
 {
     if (!p) return fail(CRSDR_EINVAL, "plan_bind_slab: NULL plan");
+    p->tail_offset = 0;
     if (!device_slab) { p->d_slab = nullptr; p->slab_stride = 0; p->hdr_first = p->hdr_count = 0; return CRSDR_OK; }
     if ((uintptr_t)device_slab % 4 || slab_stride % 4 || slab_stride < (size_t)p->row_count * (size_t)p->B || hdr_first < 0 || hdr_count < 0 ||
         hdr_first + hdr_count > p->max_batch)
@@ -903,6 +904,16 @@ extern "C" int crsdr_plan_bind_packet(crsdr_plan *p, void *device_packet, size_t
         return fail(CRSDR_EINVAL, "plan_bind_packet: matrix start and stride must be 4-byte aligned, stride >= packet bytes");
     p->d_packet = device_packet ? (int8_t *)device_packet : p->d_packet_own;
     p->packet_stride = device_packet ? packet_stride : p->own_packet_stride;
+    return CRSDR_OK;
+}
+
+// slab mode with tails (crsdr_plan_bind_slab_ex): {lag, mag, frac, phasor} of the owned rows behind the rows of every slot
+static int pack_tails(crsdr_plan *p, hipStream_t S, int nblocks, const int32_t *o_lag, const float *o_mag, const float *o_frac)
+{
+    if (!p->d_slab || !p->tail_offset) return CRSDR_OK;
+    hipLaunchKernelGGL(k_pack_tails, dim3((unsigned)((p->row_count + 255) / 256), (unsigned)nblocks), dim3(256), 0, S, p->d_slab, p->slab_stride, p->tail_offset,
+                       p->row_begin, p->row_count, p->nrows, o_lag, o_mag, o_frac, p->d_phasor);
+    HIP_TRY(hipGetLastError());
     return CRSDR_OK;
 }
 
@@ -1110,6 +1121,7 @@ extern "C" int crsdr_plan_submit_batch(crsdr_plan *p, const void *rows, int mem_
         else hipLaunchKernelGGL(k_align_fused<false>, dim3((unsigned)((1 + p->row_count) * nblocks)), dim3(kAlignThreads), 0, S, aa, fs);
         HIP_TRY(hipGetLastError());
         if (pe) HIP_TRY(hipEventRecord(pe[1], S));
+        { int rc_ = pack_tails(p, S, nblocks, o_lag, o_mag, o_frac); if (rc_) return rc_; }
         HIP_TRY(hipEventRecord(p->ev_k2done[obuf], S));
         p->k2done_valid[obuf] = true;
         p->last_locked = !any_lag;
@@ -1140,6 +1152,7 @@ extern "C" int crsdr_plan_submit_batch(crsdr_plan *p, const void *rows, int mem_
         HIP_TRY(hipGetLastError());
         if (pe) HIP_TRY(hipEventRecord(pe[1], S));
     }
+    { int rc_ = pack_tails(p, S, nblocks, o_lag, o_mag, o_frac); if (rc_) return rc_; }
     HIP_TRY(hipEventRecord(p->ev_k2done[obuf], S));
     p->k2done_valid[obuf] = true;
     p->last_locked = !any_lag;
@@ -1266,3 +1279,5 @@ extern "C" int crsdr_plan_kernel_times(crsdr_plan *p, int which, float *ms, int 
     }
     return CRSDR_OK;
 }
+
+#include "exchange_impl.hpp"

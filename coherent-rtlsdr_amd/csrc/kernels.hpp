@@ -730,6 +730,68 @@ __global__ void k_assemble_slabs(int8_t *packets, size_t packet_stride, size_t b
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < slab_words; i += (size_t)gridDim.x * blockDim.x) d[i] = s[i];
 }
 
+// ---- exchange slots (the gather carries int8 rows PLUS {lag, mag, frac, phasor} per row) ------------
+// A sharded plan in slab mode writes block t of a batch into the slot  slab + t*slab_stride:
+//   [row_count][B] int8 rows | tail at +tail_offset:  int32 lag[rc] | float mag[rc] | float frac[rc] | float2 phasor[rc]
+// (20 bytes per owned row -- what set_lag (src/ccoherent.cc:232-233) and the port-5557 payload (src/cpacketizer.cc:127,
+// 131-134) consume on the assembling side).  The rows come from the phase kernels; the tail is packed here, after them.
+__global__ void k_pack_tails(int8_t *slab, size_t slab_stride, size_t tail_offset, int row_begin, int row_count, int nrows,
+                             const int32_t *__restrict__ lag, const float *__restrict__ mag, const float *__restrict__ frac,
+                             const float2 *__restrict__ phasor)
+{
+    const int t = blockIdx.y, i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= row_count) return;
+    const size_t o = (size_t)t * nrows + row_begin + i;
+    int8_t *tail = slab + (size_t)t * slab_stride + tail_offset;
+    reinterpret_cast<int32_t *>(tail)[i] = lag[o];
+    reinterpret_cast<float *>(tail + 4 * (size_t)row_count)[i] = mag[o];
+    reinterpret_cast<float *>(tail + 8 * (size_t)row_count)[i] = frac[o];
+    const float2 ph = phasor[o];                              // written as two floats: 12*rc need not be 8-byte aligned
+    reinterpret_cast<float *>(tail + 12 * (size_t)row_count)[2 * i] = ph.x;
+    reinterpret_cast<float *>(tail + 12 * (size_t)row_count)[2 * i + 1] = ph.y;
+}
+
+// On the assembling rank: slots [nsrc][nblocks][slot_stride] (what the exchange delivers: chunk z = rank (src_base + z)'s slots
+// of the nblocks blocks assembled here; the rank's own chunk may be read straight from its send buffer: self_src) ->
+//   rows  -> matrix rows 1 + src*per .. of packet j            (unless rows_in_place: they already landed there)
+//   tails -> scalars block j:  int32 lag[nrows] | float mag[nrows] | float frac[nrows] | float phasor[nrows][2]  (row 0: zeros)
+// grid (chunks, nblocks, nsrc); W = uint4 (16-byte aligned everything) or uint32_t.
+template <typename W>
+__global__ void k_assemble_slots(int8_t *packets, size_t packet_stride, size_t body_off, int8_t *scalars, size_t scalars_stride, int nrows, int per, int B,
+                                 const int8_t *__restrict__ recv, int nblocks, size_t slot_stride, size_t tail_offset, int has_tail, int src_base,
+                                 int skip_rank, int self_rank, const int8_t *__restrict__ self_src, int rows_in_place)
+{
+    const int j = blockIdx.y, src = src_base + (int)blockIdx.z;
+    if (src == skip_rank) return;
+    const bool self = src == self_rank && self_src;
+    const int8_t *slot = self ? self_src + (size_t)j * slot_stride : recv + ((size_t)blockIdx.z * nblocks + j) * slot_stride;
+    if (!rows_in_place) {
+        const size_t words = (size_t)per * B / sizeof(W);
+        const W *s = reinterpret_cast<const W *>(slot);
+        W *d = reinterpret_cast<W *>(packets + (size_t)j * packet_stride + body_off + (size_t)src * per * B);
+        for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < words; i += (size_t)gridDim.x * blockDim.x) d[i] = s[i];
+    }
+    if (scalars && has_tail && blockIdx.x == 0) {
+        const int8_t *tail = slot + tail_offset;
+        int8_t *out = scalars + (size_t)j * scalars_stride;
+        const size_t n = (size_t)nrows, r0 = 1 + (size_t)src * per;
+        for (int i = threadIdx.x; i < per; i += blockDim.x) {
+            reinterpret_cast<int32_t *>(out)[r0 + i] = reinterpret_cast<const int32_t *>(tail)[i];
+            reinterpret_cast<float *>(out + 4 * n)[r0 + i] = reinterpret_cast<const float *>(tail + 4 * (size_t)per)[i];
+            reinterpret_cast<float *>(out + 8 * n)[r0 + i] = reinterpret_cast<const float *>(tail + 8 * (size_t)per)[i];
+            reinterpret_cast<float *>(out + 12 * n)[2 * (r0 + i)] = reinterpret_cast<const float *>(tail + 12 * (size_t)per)[2 * i];
+            reinterpret_cast<float *>(out + 12 * n)[2 * (r0 + i) + 1] = reinterpret_cast<const float *>(tail + 12 * (size_t)per)[2 * i + 1];
+        }
+        if (src == 0 && threadIdx.x == 0) {                   // row 0 (the reference channel) has no lag / phasor: zeros, like crsdr_plan_fetch
+            reinterpret_cast<int32_t *>(out)[0] = 0;
+            reinterpret_cast<float *>(out + 4 * n)[0] = 0.f;
+            reinterpret_cast<float *>(out + 8 * n)[0] = 0.f;
+            reinterpret_cast<float *>(out + 12 * n)[0] = 0.f;
+            reinterpret_cast<float *>(out + 12 * n)[1] = 0.f;
+        }
+    }
+}
+
 // ---- per-op kernels (class cdsp) ---------------------------------------------------------------
 __global__ void k_op_convtosigned(const uint32_t *in, uint32_t *out, int nwords)
 {

@@ -138,6 +138,43 @@ def rooted_blocks(T: int, world: int, rank: int) -> range:
     return range(rank * per, (rank + 1) * per)
 
 
+def slot_geometry(nrows: int, B: int, world: int) -> dict:
+    """Send-slot geometry of include/crsdr.h (crsdr_exchange_geometry), restated so that CPU-only code can use it:
+    a slot = [per][B] int8 rows | tail: int32 lag[per] | float mag[per] | float frac[per] | float phasor[per][2]."""
+    per = (nrows - 1) // world
+    if per * world != nrows - 1:
+        raise ValueError(f"{nrows - 1} signal rows do not split evenly over {world} ranks")
+    up16 = lambda v: (v + 15) // 16 * 16
+    return {"per": per, "tail_offset": per * B, "slot_stride": up16(per * B + 20 * per), "scalars_stride": up16(20 * nrows)}
+
+
+def rooted_range(nblocks: int, world: int, rank: int) -> range:
+    """Blocks of a batch of nblocks that `rank` assembles (crsdr_exchange_rooted_blocks): runs of ceil(nblocks / world);
+    the last ranks of a short batch get fewer blocks or none -- a ragged batch ships only its own bytes."""
+    bpr = -(-nblocks // world)
+    first = min(rank * bpr, nblocks)
+    return range(first, first + min(bpr, nblocks - first))
+
+
+def exchange_slots(recv, send, nblocks: int, slot_stride: int, group=None, async_op: bool = True):
+    """ONE all-to-all for a batch of nblocks blocks whose slots carry rows + per-row scalars.
+
+    send: this rank's slots [nblocks][slot_stride] bytes (written by its plan, crsdr_plan_bind_slab_ex); rank q gets the
+    slots of the blocks it roots (`rooted_range`), so the split sizes differ per peer when the batch is ragged.
+    recv: >= world * len(rooted_range(nblocks, world, rank)) * slot_stride bytes, filled [src][block][slot_stride]
+    (the layout crsdr_assemble_slots takes).  Returns the work handle (async) or None.
+    """
+    import torch.distributed as dist
+
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    counts = [len(rooted_range(nblocks, world, q)) for q in range(world)]
+    in_splits = [c * slot_stride for c in counts]
+    out_splits = [counts[rank] * slot_stride] * world
+    return dist.all_to_all_single(recv.view(-1)[: sum(out_splits)], send.view(-1)[: nblocks * slot_stride], out_splits, in_splits,
+                                  group=group, async_op=async_op)
+
+
 def exchange_batch(recv, send, group=None, async_op: bool = True):
     """One all-to-all for a whole batch.
 

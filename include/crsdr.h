@@ -238,6 +238,76 @@ int crsdr_plan_bind_slab(crsdr_plan *plan, void *device_slab, size_t slab_stride
 int crsdr_assemble_slabs(void *device_packets, size_t packet_stride, int nrows, int blocksize, const void *device_recv, int nsrc,
                          int nblocks, void *hip_stream);
 
+/* ---- exchange slots: rows + per-row scalars, one message per peer -------------------------------------
+ * The gather of SURVEY 8e carries the int8 rows PLUS 20 bytes per row of {lag, mag, frac, phasor}: what
+ * csdrdevice::set_lag (src/ccoherent.cc:232-233) and the port-5557 debug payload (src/cpacketizer.cc:127,131-134)
+ * consume on the assembling side.  crsdr_plan_bind_slab_ex is crsdr_plan_bind_slab with a TAIL per block: block t of a
+ * batch goes to the slot  device_slab + t*slab_stride =
+ *     [row_count][blocksize] int8 rows | at +tail_offset:  int32 lag[rc] | float mag[rc] | float frac[rc] | float phasor[rc][2]
+ * (tail_offset >= row_count*blocksize, 4-byte aligned, tail_offset + 20*row_count <= slab_stride; 0 = no tail).  A rank's
+ * slots of the blocks rooted on one peer are consecutive, so they travel as ONE message whatever the block count. */
+int crsdr_plan_bind_slab_ex(crsdr_plan *plan, void *device_slab, size_t slab_stride, int hdr_first, int hdr_count, size_t tail_offset);
+
+/* Slot geometry both sides of an exchange agree on (pure arithmetic, no device needed):
+ *   per = (nrows-1)/nranks rows per rank;  tail_offset = per*blocksize;  slot_stride = tail_offset + 20*per rounded up to 16;
+ *   scalars_stride = 20*nrows rounded up to 16 (one assembled scalars block per packet, layout below). */
+int crsdr_exchange_geometry(int nrows, int blocksize, int nranks, size_t *slot_stride, size_t *tail_offset, size_t *scalars_stride);
+
+/* Which rank assembles block t of a batch of nblocks blocks: blocks are dealt in runs of bpr = ceil(nblocks / nranks),
+ * root(t) = t / bpr -- rank q assembles blocks [q*bpr, min(nblocks, (q+1)*bpr)), a rotating root at batch granularity (a fixed
+ * root would ingest (G-1)/G of every block over its own xGMI links).  first/count: rank's range (count may be 0). */
+int crsdr_exchange_rooted_blocks(int nblocks, int nranks, int rank, int *first, int *count);
+
+/* On the assembling rank: recv [nsrc][nblocks][slot_stride] (chunk src = rank src's slots of the nblocks blocks assembled here,
+ * what an all-to-all of the send buffers delivers) ->  rows into matrix rows 1 + src*per .. of packet j at
+ * device_packets + j*packet_stride;  tails into the scalars block j at device_scalars + j*scalars_stride =
+ *     int32 lag[nrows] | float mag[nrows] | float frac[nrows] | float phasor[nrows][2]      (row 0: zeros, like crsdr_plan_fetch;
+ *     the phasor part is the N x complex<float> port-5557 payload as is)
+ * self_rank >= 0 with device_self != NULL: that rank's chunk is read from device_self (its own send slots) instead of recv.
+ * device_scalars may be NULL.  Asynchronous on hip_stream.  Replaces crsdr_assemble_slabs when tails travel with the rows. */
+int crsdr_assemble_slots(void *device_packets, size_t packet_stride, void *device_scalars, size_t scalars_stride, int nrows, int blocksize,
+                         const void *device_recv, int nsrc, int nblocks, size_t slot_stride, size_t tail_offset, int self_rank,
+                         const void *device_self, void *hip_stream);
+
+/* ---- the exchange itself under the C ABI: RCCL over xGMI, one process per GPU --------------------------------------
+ * librccl is resolved at run time (dlopen "librccl.so.1"): a host that never creates an exchange does not need it.
+ * The reference has no collective (its only transport is ZMQ, src/cpacketizer.cc:58-66); this is the one exchange step
+ * SURVEY 8e adds.  Rendez-vous: rank 0 calls crsdr_exchange_unique_id and hands the 128 bytes to the other ranks by
+ * whatever channel the host has (MPI, a socket, a file); every rank then calls crsdr_exchange_create. */
+#define CRSDR_EXCHANGE_ID_BYTES 128
+typedef struct crsdr_exchange crsdr_exchange;
+int crsdr_exchange_unique_id(void *id /* [CRSDR_EXCHANGE_ID_BYTES] */);
+int crsdr_exchange_create(crsdr_exchange **x, const void *id, int nranks, int rank, int device);
+int crsdr_exchange_destroy(crsdr_exchange *x);
+
+enum {
+    CRSDR_XCHG_STAGED = 0,   /* one message per peer into device_recv, then crsdr_assemble_slots (what an all-to-all does) */
+    CRSDR_XCHG_INPLACE = 1   /* rows land straight in the packet matrix (one message per block and peer, no assembly copy
+                                of remote rows); only the 20 B/row tails go through a small staging buffer */
+};
+/* One batch of nblocks blocks (every rank calls it with the same nblocks / mode, after the submit that filled device_send on
+ * hip_stream): rank q = root of blocks [q*bpr, ...) receives every rank's slots of those blocks; on return (stream order) the
+ * count packets at device_packets hold all rows and device_scalars the assembled scalars blocks.
+ *   device_send   this rank's slots [nblocks][slot_stride] (crsdr_plan_bind_slab_ex with the geometry above)
+ *   device_recv   staging of >= nranks * bpr * slot_stride bytes (CRSDR_XCHG_STAGED; may be NULL for CRSDR_XCHG_INPLACE)
+ * All RCCL calls are issued in one group on hip_stream; nothing blocks the host. */
+int crsdr_exchange_batch(crsdr_exchange *x, int mode, const void *device_send, void *device_recv, int nblocks, void *device_packets,
+                         size_t packet_stride, void *device_scalars, size_t scalars_stride, int nrows, int blocksize, void *hip_stream);
+
+/* The point-to-point operations crsdr_exchange_batch issues for (nranks, rank, nblocks, mode), in issue order -- pure host
+ * arithmetic, exported so that the matching of every send with its receive can be checked without GPUs (tests simulate the
+ * ranks and pair each rank's sends to a peer with that peer's receives from it, first in first out, as RCCL does).
+ * buffer: 0 = device_send, 1 = device_recv, 2 = device_packets, 3 = the exchange's tail staging ([nranks][bpr][20*per rounded to 16]). */
+typedef struct crsdr_xop {
+    int32_t peer;      /* the other rank */
+    int32_t is_recv;   /* 0 = send, 1 = receive */
+    int32_t buffer;    /* which buffer `offset` is relative to (above) */
+    int32_t block;     /* batch-relative block index the bytes belong to (first block for multi-block messages) */
+    uint64_t offset, bytes;
+} crsdr_xop;
+int crsdr_exchange_schedule(int nranks, int rank, int nblocks, int mode, int nrows, int blocksize, size_t packet_stride,
+                            crsdr_xop *ops, int capacity, int *count);
+
 /* With profiling enabled (CRSDR_PROFILE_SUBMIT): elapsed GPU milliseconds on the plan's stream
  * between the start and the end of the most recent submit. */
 int crsdr_plan_last_elapsed_ms(crsdr_plan *plan, float *ms);

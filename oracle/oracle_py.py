@@ -19,7 +19,8 @@ FAITHFUL, DIGITAL = 0, 1
 
 def build(force: bool = False) -> str:
     src = [os.path.join(_HERE, f) for f in ("coherent_oracle.c", "beamformer_oracle.c", "coherent_oracle.h", "Makefile")]
-    stale = force or not os.path.exists(_SO) or any(os.path.getmtime(s) > os.path.getmtime(_SO) for s in src)
+    outs = (_SO, os.path.join(_HERE, "_build", "liboracle_refflags.so"))
+    stale = force or any(not os.path.exists(o) for o in outs) or any(os.path.getmtime(s) > min(os.path.getmtime(o) for o in outs) for s in src)
     if stale:
         subprocess.run(["make", "-C", _HERE], check=True, stdout=subprocess.DEVNULL)
     return _SO
@@ -28,39 +29,53 @@ def build(force: bool = False) -> str:
 _lib = None
 
 
+def _declare(L):
+    f32p, i8p, u8p, u32p, i32p = (C.POINTER(C.c_float), C.POINTER(C.c_int8), C.POINTER(C.c_uint8),
+                                  C.POINTER(C.c_uint32), C.POINTER(C.c_int32))
+    L.orc_convtosigned.argtypes = [u8p, u8p, C.c_int]
+    L.orc_convtofloat.argtypes = [f32p, i8p, C.c_int]
+    L.orc_scalarmul.argtypes = [f32p, f32p, C.c_float, C.c_float, C.c_int]
+    L.orc_convto8bit.argtypes = [i8p, f32p, C.c_int]
+    L.orc_conj_dotproduct.argtypes = [f32p, f32p, f32p, C.c_int]
+    L.orc_magsquared.argtypes = [f32p, f32p, C.c_int]
+    L.orc_conjugatemul.argtypes = [f32p, f32p, f32p, C.c_int]
+    L.orc_indexofmax.argtypes = [f32p, C.c_int]
+    L.orc_indexofmax.restype = C.c_uint32
+    L.orc_fft.argtypes = [f32p, f32p, C.c_int, C.c_int, C.c_int]
+    L.orc_engine_create.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int]
+    L.orc_engine_create.restype = C.c_void_p
+    L.orc_engine_destroy.argtypes = [C.c_void_p]
+    L.orc_engine_reset.argtypes = [C.c_void_p]
+    L.orc_engine_block_mt.argtypes = [C.c_void_p, i8p, u32p, u8p, C.c_int, C.c_uint32,
+                                      i32p, f32p, f32p, f32p, i8p, C.c_int]
+    L.orc_packet_bytes.argtypes = [C.c_int, C.c_int]
+    L.orc_packet_bytes.restype = C.c_size_t
+    L.orc_packet_matrix_offset.argtypes = [C.c_int]
+    L.orc_packet_matrix_offset.restype = C.c_size_t
+    L.orc_covariance.argtypes = [f32p, i8p, C.c_int, C.c_int]
+    L.orc_noisesubspace.argtypes = [f32p, f32p, f32p, C.c_int]
+    L.orc_pmusic2d.argtypes = [f32p, f32p, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int, C.c_int, C.c_int]
+    return L
+
+
 def lib():
     global _lib
     if _lib is None:
         if not os.path.exists(_SO):
             build()
-        L = C.CDLL(_SO)
-        f32p, i8p, u8p, u32p, i32p = (C.POINTER(C.c_float), C.POINTER(C.c_int8), C.POINTER(C.c_uint8),
-                                      C.POINTER(C.c_uint32), C.POINTER(C.c_int32))
-        L.orc_convtosigned.argtypes = [u8p, u8p, C.c_int]
-        L.orc_convtofloat.argtypes = [f32p, i8p, C.c_int]
-        L.orc_scalarmul.argtypes = [f32p, f32p, C.c_float, C.c_float, C.c_int]
-        L.orc_convto8bit.argtypes = [i8p, f32p, C.c_int]
-        L.orc_conj_dotproduct.argtypes = [f32p, f32p, f32p, C.c_int]
-        L.orc_magsquared.argtypes = [f32p, f32p, C.c_int]
-        L.orc_conjugatemul.argtypes = [f32p, f32p, f32p, C.c_int]
-        L.orc_indexofmax.argtypes = [f32p, C.c_int]
-        L.orc_indexofmax.restype = C.c_uint32
-        L.orc_fft.argtypes = [f32p, f32p, C.c_int, C.c_int, C.c_int]
-        L.orc_engine_create.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int]
-        L.orc_engine_create.restype = C.c_void_p
-        L.orc_engine_destroy.argtypes = [C.c_void_p]
-        L.orc_engine_reset.argtypes = [C.c_void_p]
-        L.orc_engine_block_mt.argtypes = [C.c_void_p, i8p, u32p, u8p, C.c_int, C.c_uint32,
-                                          i32p, f32p, f32p, f32p, i8p, C.c_int]
-        L.orc_packet_bytes.argtypes = [C.c_int, C.c_int]
-        L.orc_packet_bytes.restype = C.c_size_t
-        L.orc_packet_matrix_offset.argtypes = [C.c_int]
-        L.orc_packet_matrix_offset.restype = C.c_size_t
-        L.orc_covariance.argtypes = [f32p, i8p, C.c_int, C.c_int]
-        L.orc_noisesubspace.argtypes = [f32p, f32p, f32p, C.c_int]
-        L.orc_pmusic2d.argtypes = [f32p, f32p, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int, C.c_int, C.c_int]
-        _lib = L
+        _lib = _declare(C.CDLL(_SO))
     return _lib
+
+
+_SO_REFFLAGS = os.path.join(_HERE, "_build", "liboracle_refflags.so")
+
+
+def lib_refflags():
+    """The same sources built with the reference's own compiler flags (-O3, no -march: CMakeLists.txt:10) -- bench.py's
+    cpu_baseline times this one; the checker is the -mavx2 build above (identical results: neither contracts to FMA)."""
+    if not os.path.exists(_SO_REFFLAGS):
+        build(force=True)
+    return _declare(C.CDLL(_SO_REFFLAGS))
 
 
 def _p(a, ty):
@@ -174,16 +189,17 @@ def pmusic2d(vec, k, d, mx, my, ncx, ncy):
 
 
 class Engine:
-    def __init__(self, nrows, B, mode=FAITHFUL, nfft_cap=0):
+    def __init__(self, nrows, B, mode=FAITHFUL, nfft_cap=0, cdll=None):
         self.nrows, self.B, self.mode = nrows, B, mode
-        self._h = lib().orc_engine_create(nrows, B, mode, nfft_cap)
+        self._L = cdll if cdll is not None else lib()
+        self._h = self._L.orc_engine_create(nrows, B, mode, nfft_cap)
         if not self._h:
             raise ValueError("orc_engine_create failed")
-        self.packet_bytes = int(lib().orc_packet_bytes(nrows, B))
-        self.matrix_offset = int(lib().orc_packet_matrix_offset(nrows))
+        self.packet_bytes = int(self._L.orc_packet_bytes(nrows, B))
+        self.matrix_offset = int(self._L.orc_packet_matrix_offset(nrows))
 
     def reset(self):
-        lib().orc_engine_reset(self._h)
+        self._L.orc_engine_reset(self._h)
 
     def block(self, rows, readcnt=None, lag_mask=None, refnoise_enabled=True, seq=0, nthreads=1,
               want_packet=True):
@@ -196,7 +212,7 @@ class Engine:
         pkt = np.zeros(self.packet_bytes, dtype=np.int8) if want_packet else None
         rc_arr = None if readcnt is None else np.ascontiguousarray(readcnt, dtype=np.uint32)
         mk = None if lag_mask is None else np.ascontiguousarray(lag_mask, dtype=np.uint8)
-        rc = lib().orc_engine_block_mt(self._h, _p(rows, C.c_int8), _p(rc_arr, C.c_uint32), _p(mk, C.c_uint8),
+        rc = self._L.orc_engine_block_mt(self._h, _p(rows, C.c_int8), _p(rc_arr, C.c_uint32), _p(mk, C.c_uint8),
                                        int(bool(refnoise_enabled)), int(seq), _p(lag, C.c_int32),
                                        _p(mag, C.c_float), _p(frac, C.c_float), _p(ph, C.c_float),
                                        _p(pkt, C.c_int8), int(nthreads))
@@ -207,7 +223,7 @@ class Engine:
 
     def close(self):
         if self._h:
-            lib().orc_engine_destroy(self._h)
+            self._L.orc_engine_destroy(self._h)
             self._h = None
 
     def __del__(self):

@@ -144,6 +144,80 @@ def _worker_a2a(rank, world, port, nsig, L, T, outdir):
     dist.destroy_process_group()
 
 
+def _worker_slots(rank, world, port, nsig, L, T, outdir):
+    """The exchange bench.py runs: slots = owned rows + the 20 B/row tail {lag, mag, frac, phasor} (what set_lag and the
+    port-5557 payload need on the assembling rank, src/ccoherent.cc:232-233, src/cpacketizer.cc:127), ONE all-to-all with
+    per-peer split sizes (a ragged batch ships only its own bytes), then assembly by the index contract of
+    crsdr_assemble_slots (restated in numpy here; the kernel itself is tested on the GPU against the same contract)."""
+    for p in (ROOT, os.path.join(ROOT, "oracle")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sharding = importlib.import_module("coherent-rtlsdr_amd.sharding")
+    synth = importlib.import_module("coherent-rtlsdr_amd.synth")
+    import oracle_py as O
+
+    nrows, B = nsig + 1, 2 * L
+    slab = sharding.slab_for_rank(nrows, world, rank)
+    geo = sharding.slot_geometry(nrows, B, world)
+    per, slot, toff = geo["per"], geo["slot_stride"], geo["tail_offset"]
+    params = synth.RowParams(nsig, L, 58, dmax=L // 8)
+    eng = O.Engine(nrows, B, O.DIGITAL)
+    mask = np.zeros(nrows, dtype=np.uint8)
+    own = slice(slab.row_begin, slab.row_begin + slab.row_count)
+    mask[own] = 1
+    mine = sharding.rooted_range(T, world, rank)
+    send = np.zeros(T * slot, dtype=np.uint8)
+    packets = {}
+    for t in range(T):
+        rows, _ = synth.make_block(nsig, L, 58, t, params=params)
+        out = eng.block(rows, seq=t, lag_mask=mask)
+        s = send[t * slot: (t + 1) * slot]
+        s[:per * B] = out["matrix"][own].reshape(-1).view(np.uint8)
+        s[toff: toff + 4 * per] = out["lag"][own].view(np.uint8)
+        s[toff + 4 * per: toff + 8 * per] = out["mag"][own].view(np.uint8)
+        s[toff + 8 * per: toff + 12 * per] = out["frac"][own].view(np.uint8)
+        s[toff + 12 * per: toff + 20 * per] = out["phasor"][own].view(np.uint8)
+        if t in mine:                                                          # header + readcnt + row 0 only where rooted
+            pkt = out["packet"].copy()
+            pkt[16 + 4 * nrows + B:] = 99
+            packets[t] = pkt
+    recv = torch.full((max(1, world * len(mine) * slot),), 55, dtype=torch.uint8)
+    w = sharding.exchange_slots(recv, torch.from_numpy(send), T, slot, async_op=True)
+    w.wait()
+    r = recv.numpy()
+    for j, t in enumerate(mine):
+        m = packets[t][16 + 4 * nrows:].reshape(nrows, B)
+        lag, mag, frac = np.zeros(nrows, np.int32), np.zeros(nrows, np.float32), np.zeros(nrows, np.float32)
+        ph = np.zeros(nrows, np.complex64)
+        for src in range(world):
+            sl = r[(src * len(mine) + j) * slot: (src * len(mine) + j + 1) * slot]
+            rr = slice(1 + src * per, 1 + (src + 1) * per)
+            m[rr] = sl[:per * B].view(np.int8).reshape(per, B)
+            lag[rr], mag[rr] = sl[toff: toff + 4 * per].view(np.int32), sl[toff + 4 * per: toff + 8 * per].view(np.float32)
+            frac[rr], ph[rr] = sl[toff + 8 * per: toff + 12 * per].view(np.float32), sl[toff + 12 * per: toff + 20 * per].view(np.complex64)
+        np.savez(os.path.join(outdir, f"slot_{t}.npz"), packet=packets[t], lag=lag, mag=mag, frac=frac, phasor=ph)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,T", [(2, 8), (4, 8), (4, 6), (2, 3)])
+def test_slot_exchange_carries_rows_and_per_row_scalars(world, T, tmp_path, oracle, synth):
+    # T = 6 over 4 ranks and T = 3 over 2: ragged batches (runs of 2 -> the last rank roots fewer blocks / none)
+    nsig, L = 8, 256
+    mp.spawn(_worker_slots, args=(world, _free_port(), nsig, L, T, str(tmp_path)), nprocs=world, join=True)
+    params = synth.RowParams(nsig, L, 58, dmax=L // 8)
+    eng = oracle.Engine(nsig + 1, 2 * L, oracle.DIGITAL)
+    for t in range(T):
+        rows, _ = synth.make_block(nsig, L, 58, t, params=params)
+        exp = eng.block(rows, seq=t)
+        got = np.load(tmp_path / f"slot_{t}.npz")
+        assert np.array_equal(got["packet"], exp["packet"]), t
+        for k in ("lag", "mag", "frac", "phasor"):
+            assert np.array_equal(got[k][1:], exp[k][1:]), (t, k)
+
+
 @pytest.mark.parametrize("world", [2, 4])
 def test_one_all_to_all_per_batch_reassembles_every_packet(world, tmp_path, oracle, synth):
     nsig, L, T = 8, 256, 8
