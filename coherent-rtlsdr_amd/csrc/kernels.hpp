@@ -353,7 +353,7 @@ __device__ __forceinline__ uint32_t rotq_word(uint32_t s, float2 p)
     // then y * 127 [v_pk_mul], round-half-even, and  +128 -> v_cvt_pk_u8_f32 (saturating to [0, 255] = the clamp)
     // straight into the byte lane; one XOR turns the four offset-binary bytes back into two's complement.
     const c2 pp = c2{p.x, p.y};
-    uint32_t out = 0u;
+    uint32_t out;
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
         c2 x = c2{(float)sext8(s, 2 * h), (float)sext8(s, 2 * h + 1)};
@@ -366,7 +366,9 @@ __device__ __forceinline__ uint32_t rotq_word(uint32_t s, float2 p)
         // round first, then let v_cvt_pk_u8_f32 saturate: rint(clamp(x)) == clamp(rint(x)) on [-128, 127] (ties to even keep
         // 127.5 -> 128 -> 127 and -128.5 -> -128), and r + 128 is exact, so the explicit clamp of cdsp::convto8bit is implied
         const c2 u = c2{rintf(y.x), rintf(y.y)} + 128.0f;
-        asm("v_cvt_pk_u8_f32 %0, %1, %2, %0" : "+v"(out) : "v"(u.x), "n"(2 * h));
+        // byte 0 first: its "old" operand may be anything (all four bytes get written), so no zero has to be materialised
+        if (h == 0) asm("v_cvt_pk_u8_f32 %0, %1, 0, %1" : "=v"(out) : "v"(u.x));
+        else asm("v_cvt_pk_u8_f32 %0, %1, %2, %0" : "+v"(out) : "v"(u.x), "n"(2 * h));
         asm("v_cvt_pk_u8_f32 %0, %1, %2, %0" : "+v"(out) : "v"(u.y), "n"(2 * h + 1));
     }
     return out ^ 0x80808080u;
@@ -510,9 +512,12 @@ constexpr unsigned long long kChainEmpty = ~0ull;
 constexpr int kFusedSpinLimit = 2048;      // polls of ~1 us each before a workgroup stops waiting and computes the value itself
 
 // FULL: B == 16384, every thread owns exactly four 16-byte vectors of the row (no bounds checks in the hot loops)
-template <bool FULL>
-__global__ __launch_bounds__(kAlignThreads, 8) void k_align_fused(AlignArgs a, FusedSync fs)
+// XOR: the input is offset binary (CRSDR_OFFSET_BINARY); false folds the 40-odd "^ xor80" of a thread away (5 % of its VALU work)
+template <bool FULL, bool XOR>
+__global__ __launch_bounds__(kAlignThreads, 8) void k_align_fused(AlignArgs a_, FusedSync fs)
 {
+    AlignArgs a = a_;
+    a.xor80 = XOR ? a_.xor80 : 0u;                 // a compile-time zero without XOR
     __shared__ long long sred[2 * (kAlignThreads / 64)];
     __shared__ float2 sp;
     __shared__ unsigned long long smiss, sfix[64];
@@ -560,14 +565,29 @@ __global__ __launch_bounds__(kAlignThreads, 8) void k_align_fused(AlignArgs a, F
             rv[q] = r128[(FULL || i < nvec) ? i : 0];
         }
     }
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    typedef u32x4 u32x4_u2 __attribute__((aligned(2)));
+    if (a.nt & 2) {            // ONE uniform branch around all four loads (a branch per load would serialise them)
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int i = tid + q * kAlignThreads;
-        const int m0 = 8 * i + d;
-        const bool inside = (FULL || i < nvec) && m0 >= 0 && m0 + 8 <= L;
-        const u4_unaligned u = *reinterpret_cast<const u4_unaligned *>(srow + 2 * (ptrdiff_t)(inside ? m0 : 0));
-        sv[q] = make_uint4(u.x, u.y, u.z, u.w);
-        edge |= !inside;
+        for (int q = 0; q < 4; ++q) {
+            const int i = tid + q * kAlignThreads;
+            const int m0 = 8 * i + d;
+            const bool inside = (FULL || i < nvec) && m0 >= 0 && m0 + 8 <= L;
+            // the row is read once: non-temporal, out of the way of the reference row in L2 / the memory-side cache
+            const u32x4 u = __builtin_nontemporal_load(reinterpret_cast<const u32x4_u2 *>(srow + 2 * (ptrdiff_t)(inside ? m0 : 0)));
+            sv[q] = make_uint4(u.x, u.y, u.z, u.w);
+            edge |= !inside;
+        }
+    } else {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int i = tid + q * kAlignThreads;
+            const int m0 = 8 * i + d;
+            const bool inside = (FULL || i < nvec) && m0 >= 0 && m0 + 8 <= L;
+            const u4_unaligned u = *reinterpret_cast<const u4_unaligned *>(srow + 2 * (ptrdiff_t)(inside ? m0 : 0));
+            sv[q] = make_uint4(u.x, u.y, u.z, u.w);
+            edge |= !inside;
+        }
     }
     if (edge) {
 #pragma unroll
@@ -713,7 +733,16 @@ __global__ __launch_bounds__(kAlignThreads, 8) void k_align_fused(AlignArgs a, F
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const int i = tid + q * kAlignThreads;
-        if (FULL || i < nvec) o128[i] = make_uint4(rotq_word(sv[q].x, p), rotq_word(sv[q].y, p), rotq_word(sv[q].z, p), rotq_word(sv[q].w, p));
+        if (FULL || i < nvec) {
+#ifdef CRSDR_K2_EXPERIMENT     // diagnostics only (tools/k2_ab.py with a -DCRSDR_K2_EXPERIMENT build): bit 4 copy instead of rotate, bit 5 no stores
+            if (a.nt & 32) { if (sv[q].x == 0x12345678u && p.x == 123.f) o128[i] = sv[q]; continue; }
+            const uint4 v = (a.nt & 16) ? sv[q] : make_uint4(rotq_word(sv[q].x, p), rotq_word(sv[q].y, p), rotq_word(sv[q].z, p), rotq_word(sv[q].w, p));
+#else
+            const uint4 v = make_uint4(rotq_word(sv[q].x, p), rotq_word(sv[q].y, p), rotq_word(sv[q].z, p), rotq_word(sv[q].w, p));
+#endif
+            if (a.nt & 1) __builtin_nontemporal_store(u32x4{v.x, v.y, v.z, v.w}, reinterpret_cast<u32x4 *>(o128 + i));   // written once, read by nobody here
+            else o128[i] = v;
+        }
     }
 }
 

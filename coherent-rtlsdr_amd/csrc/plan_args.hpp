@@ -62,6 +62,7 @@ struct AlignArgs {
     float2 *phasor;           // [T][nrows] get_phasecorrect() after each block
     int nrows, B, row_begin, nblocks;
     int digital, refnoise, xcorr_ran;
+    int nt;                   // bit 0: non-temporal stores of the output rows, bit 1: non-temporal loads of the signal rows (both are touched once)
     uint32_t seq, xor80;
     // slab output (sharded plans, crsdr_plan_bind_slab): when slab != nullptr the owned rows of block t go to
     // slab + t*slab_stride (row_begin first, B-byte pitch) instead of the packet matrix, and header + readcnt +

@@ -16,14 +16,9 @@ void ccontrol::on_block()
     if (dev->get_synchronized()) return;                // wait_synchronized() :89
     if (dev->is_lagrequested()) return;                 // the requested lag has not arrived yet
     const float lag = dev->get_lagp()->lag;             // :93
-    const float fs = dev->get_samplerate();
-    const double block_seconds = (double)(dev->get_blocksize() >> 1) / fs;
-    if (std::fabs(lag) > sync_threshold) {              // :99
-        const float p = descent(lag);                   // :101
-        const double t = frac_t * std::fabs(lag / (p * fs)); // :102 time to spend at the altered sample rate
-        dev->set_correction_f(p);                       // :108
-        hold_blocks = (int)std::ceil(t / block_seconds);
-        if (hold_blocks < 1) hold_blocks = 1;
+    if (needs_correction(lag)) {                        // :99
+        dev->set_correction_f(descent(lag));            // :101,108
+        hold_blocks = hold_block_count(lag, (uint32_t)dev->get_samplerate(), dev->get_blocksize());   // :102,110 in block time
         correcting = true;
     } else {
         dev->set_correction_f(0.0f);                    // :116-117

@@ -50,7 +50,9 @@ int main(int argc, char **argv)
 {
     int nsig = 3, L = 8192, blocks = 12, mode = CRSDR_MODE_DIGITAL, dmax = -1;
     std::string dump, zmqaddr;
-    bool run_cdsp = false, servo = false, threads = false, music = false;
+    bool run_cdsp = false, servo = false, threads = false, music = false, servo_table = false;
+    std::vector<double> table_lags;
+    int table_fs = 2048000;
     std::string replay;
     int pace_ms = 0;
     for (int i = 1; i < argc; ++i) {
@@ -70,8 +72,25 @@ int main(int argc, char **argv)
         else if (a == "--pace-ms") val(pace_ms);
         else if (a == "--replay" && i + 1 < argc) { replay = argv[++i]; threads = true; }   // <prefix><row>.u8: raw uint8 IQ recordings (f2)
         else if (a == "--music") music = true;      // f4: the last packet through the beamformer chain (needs nsig = 7 x 3)
+        else if (a == "--fs") val(table_fs);
+        else if (a == "--servo-table" && i + 1 < argc) {      // comma-separated lags
+            servo_table = true;
+            for (char *tok = std::strtok(argv[++i], ","); tok; tok = std::strtok(nullptr, ",")) table_lags.push_back(std::atof(tok));
+        }
     }
     int fails = 0;
+    if (servo_table) {
+        // f3, numbers only (no device): descent / hold time / hold blocks of the servo for every lag given after the flag,
+        // printed with full precision for tests/test_host_cpp.py to compare with its restatement of src/ccontrol.cc
+        for (double lg : table_lags) {
+            const float lag = (float)lg;
+            std::printf("servo lag %.9g correct %d p %.9g t %.17g blocks %d realfs %.17g\n", lag, (int)ccontrol::needs_correction(lag),
+                        ccontrol::descent(lag), ccontrol::needs_correction(lag) ? ccontrol::hold_seconds(lag, (uint32_t)table_fs) : 0.0,
+                        ccontrol::needs_correction(lag) ? ccontrol::hold_block_count(lag, (uint32_t)table_fs, 2 * (uint32_t)L) : 0,
+                        ccontrol::realfs((uint32_t)table_fs));
+        }
+        return 0;
+    }
     if (run_cdsp) fails += cdsp_selftest();
 
     const uint32_t B = 2 * (uint32_t)L;

@@ -55,6 +55,55 @@ def test_block_ring_under_overrun_never_tears_a_block(host_build):
     assert r.returncode == 0 and "RING OK" in r.stdout, r.stdout + r.stderr
 
 
+def _servo_restatement(lag, samplerate, blocksize):
+    """src/ccontrol.cc:25-29,36-45,73-76,99-119 with the reference's own types: lag, scale, frac_t, p, fs and the
+    quotient lag / (p * fs) are float (unqualified tanh / fabs of a float pick the float overloads in C++), maxppm is
+    double 2^13 / 2^24, t is a double holding a float product; include/common.h:32 sync_threshold = 0.005f."""
+    f32 = np.float32
+    lag = f32(lag)
+    xtal22 = 28800000.0 * 4194304.0
+    fsratio = int(xtal22 / samplerate) & 0x0ffffffc                    # realfs(): :36-45
+    real_fsratio = fsratio | ((fsratio & 0x08000000) << 1)
+    realfs = xtal22 / real_fsratio
+    correct = bool(np.abs(lag) > f32(0.005))                           # :99
+    p = f32((2.0 ** 13 / 2.0 ** 24) * float(np.tanh(lag / f32(100.0))))   # descent(): :73-76
+    if not correct:
+        return correct, float(p), 0.0, 0, realfs
+    t = float(f32(0.90) * np.abs(lag / (p * f32(realfs))))             # :102
+    block_s = (blocksize // 2) / samplerate                            # the model's clock: one block = L / fs seconds
+    return correct, float(p), t, max(1, int(np.ceil(t / block_s))), realfs
+
+
+@pytest.mark.parametrize("fs", [2048000, 1000000, 250000])
+def test_servo_numbers_match_the_reference_formulas(host_build, fs):
+    # SURVEY 8 f3, numeric: ccontrol::descent, the hold time at the altered sample rate and its block-quantised count,
+    # over a lag grid that includes both sides of sync_threshold (0.005: at the threshold itself the row is marked
+    # synchronized, src/ccontrol.cc:99,116-119), small lags (hold ~ 0.9 * 100 * 2^11 / fs whatever the lag), the knee of
+    # the tanh and full-scale lags (p saturates at 2^-11, hold grows linearly)
+    lags = [0.004, 0.005, 0.0050001, 0.0051, -0.0051, 0.01, 0.5, 1, -1, 2, -7, 13, 50, -99, 100, 150, 250, -400, 1000, 2048, -4095, 8191, -8192]
+    L = 8192
+    r = subprocess.run([os.path.join(host_build, "coherent_demo"), "--L", str(L), "--fs", str(fs), "--servo-table", ",".join(repr(x) for x in lags)],
+                       capture_output=True, text=True, timeout=60)
+    assert r.returncode == 0, r.stdout + r.stderr
+    rows = [ln.split() for ln in r.stdout.splitlines() if ln.startswith("servo lag")]
+    assert len(rows) == len(lags)
+    for lag, w in zip(lags, rows):
+        got = dict(zip(w[1::2], w[2::2]))
+        correct, p, t, nblk, realfs = _servo_restatement(lag, fs, 2 * L)
+        assert np.float32(float(got["lag"])) == np.float32(lag)
+        assert int(got["correct"]) == int(correct), lag
+        assert abs(float(got["p"]) - p) <= 2e-7 * abs(p), (lag, got["p"], p)          # float tanh: libm vs numpy, <= 1 ulp
+        assert abs(float(got["realfs"]) - realfs) <= 1e-9 * realfs
+        if correct:
+            assert abs(float(got["t"]) - t) <= 4e-7 * t, (lag, got["t"], t)
+            assert abs(int(got["blocks"]) - nblk) <= (1 if abs(t / ((L) / fs) - round(t / (L / fs))) < 1e-5 else 0), (lag, got["blocks"], nblk)
+            assert np.sign(float(got["p"])) == np.sign(lag)                           # the resampler is slewed TOWARDS zero lag
+    # anchors: below the tanh knee the hold time does not depend on the lag: 0.9 * 100 * 2^11 / fs
+    _, _, t1, n1, _ = _servo_restatement(1.0, fs, 2 * L)
+    assert abs(t1 - 0.9 * 100 * 2048 / _servo_restatement(1.0, fs, 2 * L)[4]) < 1e-4 * t1
+    assert n1 == int(np.ceil(t1 / (L / fs)))
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("args", [["--cdsp", "--blocks", "12"], ["--faithful", "--blocks", "3"],
                                   ["--nsig", "21", "--L", "8192", "--blocks", "12"]])
