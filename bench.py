@@ -45,6 +45,7 @@ def parse():
                     "0 = 64, the plan's maximum (measured on one GPU: 16.5 k blocks/s at 8, 17.1 k at 16, 17.6 k at 64)")
     ap.add_argument("--mode", choices=["digital", "faithful"], default="digital")
     ap.add_argument("--cfg5", action="store_true", help="BASELINE config 5 instead: 1 + 21 rows x 2^20 samples (long-block path)")
+    ap.add_argument("--frac-apply", action="store_true", help="with --cfg5: fractional-delay correction on (crsdr_plan_set_frac_apply, D = this block's estimate)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the locked-mode / large-working-set extras")
     ap.add_argument("--cpu-blocks", type=int, default=0, help="oracle blocks to time (0 = auto, ~10-20 s)")
@@ -117,6 +118,8 @@ def main():
     plan = b.Plan(nrows, B, mode, device=local_rank, row_begin=slab.row_begin, row_count=slab.row_count, max_batch=T)
     stream = torch.cuda.current_stream()
     plan.set_stream(stream.cuda_stream)
+    if args.cfg5 and args.frac_apply:
+        plan.set_frac_apply(True, 1.0, None)
     # NSETS ring-buffered output sets (the exchange of batch i runs under the compute of batch i+1); the matrix
     # of every packet is 16-byte aligned.  One GPU: T packets per set.  Several GPUs: per set one slot buffer
     # [T][slot_stride] (rows + the 20 B/row {lag, mag, frac, phasor} tail of the rank's slab: the all-to-all's send side),

@@ -32,7 +32,7 @@ ABI_SYMBOLS = [
     "crsdr_noisesubspace", "crsdr_pmusic2d", "crsdr_plan_bind_slab", "crsdr_assemble_slabs",
     "crsdr_device_info", "crsdr_host_alloc", "crsdr_host_free",
     "crsdr_plan_bind_slab_ex", "crsdr_exchange_geometry", "crsdr_exchange_rooted_blocks", "crsdr_assemble_slots",
-    "crsdr_exchange_unique_id", "crsdr_exchange_create", "crsdr_exchange_destroy", "crsdr_exchange_batch", "crsdr_exchange_schedule",
+    "crsdr_plan_set_frac_apply", "crsdr_exchange_unique_id", "crsdr_exchange_create", "crsdr_exchange_destroy", "crsdr_exchange_batch", "crsdr_exchange_schedule",
 ]
 XCHG_STAGED, XCHG_INPLACE = 0, 1
 EXCHANGE_ID_BYTES = 128
@@ -120,6 +120,7 @@ def lib():
     L.crsdr_assemble_slabs.argtypes = [vp, C.c_size_t, C.c_int, C.c_int, vp, C.c_int, C.c_int, vp]
     L.crsdr_plan_submit_batch.argtypes = [vp, vp, C.c_int, C.c_int, C.c_size_t, u32p, u8p, C.c_uint32, C.c_uint32]
     szp = C.POINTER(C.c_size_t)
+    L.crsdr_plan_set_frac_apply.argtypes = [vp, C.c_int, C.c_float, f32p]
     L.crsdr_plan_bind_slab_ex.argtypes = [vp, vp, C.c_size_t, C.c_int, C.c_int, C.c_size_t]
     L.crsdr_exchange_geometry.argtypes = [C.c_int, C.c_int, C.c_int, szp, szp, szp]
     L.crsdr_exchange_rooted_blocks.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
@@ -450,6 +451,11 @@ class Plan:
     def bind_slab(self, device_ptr: int | None, slab_stride: int = 0, hdr_first: int = 0, hdr_count: int = 0):
         """Slab output for sharded plans (crsdr_plan_bind_slab); None returns to packet output."""
         _check(lib().crsdr_plan_bind_slab(self._h, C.c_void_p(device_ptr or 0), int(slab_stride), int(hdr_first), int(hdr_count)))
+
+    def set_frac_apply(self, enable=True, gain=1.0, frac_override=None):
+        """crsdr_plan_set_frac_apply: fractional-delay correction of the matrix rows (long-block plans, digital mode)."""
+        ov = None if frac_override is None else np.ascontiguousarray(frac_override, dtype=np.float32)
+        _check(lib().crsdr_plan_set_frac_apply(self._h, int(bool(enable)), C.c_float(gain), _p(ov, C.c_float)))
 
     def bind_slab_ex(self, device_ptr: int | None, slab_stride: int = 0, hdr_first: int = 0, hdr_count: int = 0, tail_offset: int = 0):
         """crsdr_plan_bind_slab_ex: slab output with the per-row {lag, mag, frac, phasor} tail behind the rows of every slot."""

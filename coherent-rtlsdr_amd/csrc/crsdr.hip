@@ -305,11 +305,34 @@ static hipError_t launch_long_rows(hipStream_t s, int n1, int nrows_launch, floa
         hipLaunchKernelGGL(kern, dim3(n1, nrows_launch), dim3(x14::THREADS), x14::LDS_BYTES, s, Y, twA, twB, (float4 *)refspec);
         return hipGetLastError();
     }
-    auto kern = x14p::k_rows14_cf32p<IS_REF>;
+    auto kern = x14p::k_rows14_cf32p<IS_REF, false>;
     hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, x14::LDS_BYTES);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(kern, dim3(n1, nrows_launch), dim3(x14::THREADS), x14::LDS_BYTES, s, reinterpret_cast<c2 *>(Y), reinterpret_cast<const c2 *>(twA),
-                       reinterpret_cast<const c2 *>(twB), (float4 *)refspec);
+                       reinterpret_cast<const c2 *>(twB), (float4 *)refspec, x14p::RampArgs{});
+    return hipGetLastError();
+}
+// apply pass of crsdr_plan_set_frac_apply: row transforms with the row's fractional-delay response, then column transforms to int8
+static hipError_t launch_long_rows_ramp(hipStream_t s, int n1, int nrows_launch, float2 *Y, const float2 *twA, const float2 *twB, const x14p::RampArgs &ra)
+{
+    auto kern = x14p::k_rows14_cf32p<false, true>;
+    hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, x14::LDS_BYTES);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(kern, dim3(n1, nrows_launch), dim3(x14::THREADS), x14::LDS_BYTES, s, reinterpret_cast<c2 *>(Y), reinterpret_cast<const c2 *>(twA),
+                       reinterpret_cast<const c2 *>(twB), (float4 *)nullptr, ra);
+    return hipGetLastError();
+}
+static hipError_t launch_long_rows_ref1(hipStream_t s, float2 *Y, const float2 *twA, const float2 *twB, float2 *refspec)
+{
+    return launch_long_rows<true>(s, 1, 1, Y, twA, twB, refspec);
+}
+template <int LOG2N1>
+static hipError_t launch_long_out_cols(hipStream_t s, int nrows_launch, const float2 *Z, const lb::LongTw &tw, int8_t *out)
+{
+    auto kern = lb::k_long_inv_cols<LOG2N1, true>;
+    hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lb::LDS_BYTES);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(kern, dim3(lb::ntiles(LOG2N1), nrows_launch), dim3(lb::THREADS), lb::LDS_BYTES, s, Z, tw, (lb::LongPartial *)nullptr, out);
     return hipGetLastError();
 }
 template <int LOG2N1>
@@ -318,7 +341,7 @@ static hipError_t launch_long_inv_cols(hipStream_t s, int nrows_launch, const fl
     auto kern = lb::k_long_inv_cols<LOG2N1>;
     hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lb::LDS_BYTES);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(kern, dim3(lb::ntiles(LOG2N1), nrows_launch), dim3(lb::THREADS), lb::LDS_BYTES, s, Z, tw, part);
+    hipLaunchKernelGGL(kern, dim3(lb::ntiles(LOG2N1), nrows_launch), dim3(lb::THREADS), lb::LDS_BYTES, s, Z, tw, part, (int8_t *)nullptr);
     return hipGetLastError();
 }
 
@@ -639,6 +662,11 @@ struct crsdr_plan {
     float2 *d_wc = nullptr, *d_wf = nullptr, *d_tw1 = nullptr, *d_Y = nullptr, *d_Yref = nullptr;
     lb::LongPartial *d_part = nullptr;
     int long_chunk = 1 << 30; // rows per pass of the long-block stages
+    // fractional-delay correction (crsdr_plan_set_frac_apply; long blocks, digital mode)
+    bool frac_apply = false, frac_override_on = false;
+    float frac_gain = 1.0f;
+    float *d_frac_override = nullptr;   // [nrows]
+    uint32_t *d_k2tab = nullptr;        // [8192] frequency index k2 of every junction register pair of the row transforms
     // pinned staging ring for the small per-batch host arrays
     uint32_t *h_readcnt = nullptr;
     uint8_t *h_mask = nullptr;
@@ -682,6 +710,39 @@ static int plan_init_state(crsdr_plan *p)
     p->phase_cur = 0;
     p->last_nblocks = 0;
     p->snap_valid = false;
+    return CRSDR_OK;
+}
+
+static hipError_t launch_long_rows_ref1(hipStream_t s, float2 *Y, const float2 *twA, const float2 *twB, float2 *refspec);
+// Which frequency k2 of the 16384-point row transform sits in which junction register?  Transform a one-hot line
+// x[n] = delta[n - 1] with the reference-row form of the kernel (forward, conj, refspec layout): slot q then holds
+// exp(+2 pi i k2 / 16384) twice over, and k2 is read off the angle.  Done once per long-block plan; the table must be a
+// permutation of 0 .. 16383 or the plan is refused.
+static int make_k2tab(crsdr_plan *p)
+{
+    const size_t N2 = lb::N2;
+    HIP_TRY(hipMemset(p->d_Yref, 0, sizeof(float2) * N2));
+    const float2 one = make_float2(1.0f, 0.0f);
+    HIP_TRY(hipMemcpy(p->d_Yref + 1, &one, sizeof(one), hipMemcpyHostToDevice));
+    HIP_TRY(hipDeviceSynchronize());       // the plan's streams are non-blocking: no implicit order with the null stream
+    HIP_TRY(launch_long_rows_ref1(p->own_stream, p->d_Yref, p->d_twA, p->d_twB, p->d_refspec[0]));
+    HIP_TRY(hipStreamSynchronize(p->own_stream));
+    std::vector<float2> h(N2);
+    HIP_TRY(hipMemcpy(h.data(), p->d_refspec[0], sizeof(float2) * N2, hipMemcpyDeviceToHost));
+    std::vector<uint32_t> tab(N2 / 2);
+    std::vector<unsigned char> seen(N2, 0);
+    for (size_t i = 0; i < N2; ++i) {
+        const double rev = std::atan2((double)h[i].y, (double)h[i].x) / (2.0 * M_PI);      // conj(W^k2) = exp(+2 pi i k2 / N2)
+        const long k2 = ((long)std::llround(rev * (double)N2) % (long)N2 + (long)N2) % (long)N2;
+        const double mag = std::hypot((double)h[i].x, (double)h[i].y);
+        if (std::fabs(mag - 1.0) > 1e-3 || seen[(size_t)k2]) return fail(CRSDR_EHIP, "plan_create: frequency map of the row transform is not a permutation (entry %zu)", i);
+        seen[(size_t)k2] = 1;
+        if (i & 1) tab[i >> 1] |= (uint32_t)k2 << 16; else tab[i >> 1] = (uint32_t)k2;
+    }
+    HIP_TRY(hipMalloc((void **)&p->d_k2tab, sizeof(uint32_t) * tab.size()));
+    HIP_TRY(hipMemcpy(p->d_k2tab, tab.data(), sizeof(uint32_t) * tab.size(), hipMemcpyHostToDevice));
+    HIP_TRY(hipMalloc((void **)&p->d_frac_override, sizeof(float) * (size_t)p->nrows));
+    HIP_TRY(hipMemset(p->d_frac_override, 0, sizeof(float) * (size_t)p->nrows));
     return CRSDR_OK;
 }
 
@@ -751,6 +812,7 @@ static int plan_alloc(crsdr_plan *p)
     }
     HIP_TRY(hipHostMalloc((void **)&p->h_readcnt, sizeof(uint32_t) * n * T * kStageSlots, hipHostMallocDefault));
     HIP_TRY(hipHostMalloc((void **)&p->h_mask, n * kStageSlots, hipHostMallocDefault));
+    if (p->longblock) { int rc = make_k2tab(p); if (rc) return rc; }
     return plan_init_state(p);
 }
 
@@ -761,7 +823,7 @@ static void plan_free(crsdr_plan *p)
     if (p->own_stream) (void)hipStreamSynchronize(p->own_stream);
     if (p->aux) (void)hipStreamSynchronize(p->aux);
     if (p->xs) (void)hipStreamSynchronize(p->xs);
-    void *bufs[] = {p->d_wc, p->d_wf, p->d_tw1, p->d_Y, p->d_Yref, p->d_part, p->d_tw, p->d_twA, p->d_twB, p->d_refspec[0], p->d_refspec[1], p->d_rows, p->d_packet_alloc, p->d_readcnt,
+    void *bufs[] = {p->d_frac_override, p->d_k2tab, p->d_wc, p->d_wf, p->d_tw1, p->d_Y, p->d_Yref, p->d_part, p->d_tw, p->d_twA, p->d_twB, p->d_refspec[0], p->d_refspec[1], p->d_rows, p->d_packet_alloc, p->d_readcnt,
                     p->d_mask, p->d_lag, p->d_mag, p->d_frac, p->d_phasor, p->d_corr, p->d_sync, p->d_state, p->d_state_snap};
     for (void *b : bufs) if (b) (void)hipFree(b);
     if (p->h_readcnt) (void)hipHostFree(p->h_readcnt);
@@ -904,6 +966,23 @@ extern "C" int crsdr_plan_bind_packet(crsdr_plan *p, void *device_packet, size_t
         return fail(CRSDR_EINVAL, "plan_bind_packet: matrix start and stride must be 4-byte aligned, stride >= packet bytes");
     p->d_packet = device_packet ? (int8_t *)device_packet : p->d_packet_own;
     p->packet_stride = device_packet ? packet_stride : p->own_packet_stride;
+    return CRSDR_OK;
+}
+
+extern "C" int crsdr_plan_set_frac_apply(crsdr_plan *p, int enable, float gain, const float *frac_override)
+{
+    if (!p) return fail(CRSDR_EINVAL, "plan_set_frac_apply: NULL plan");
+    if (!enable) { p->frac_apply = false; return CRSDR_OK; }
+    if (!p->longblock || p->mode != CRSDR_MODE_DIGITAL)
+        return fail(CRSDR_EINVAL, "plan_set_frac_apply: needs a long-block plan (blocksize > 16384) in CRSDR_MODE_DIGITAL");
+    if (!(gain == gain)) return fail(CRSDR_EINVAL, "plan_set_frac_apply: gain is NaN");
+    HIP_TRY(hipSetDevice(p->device));
+    if (frac_override) {
+        int rc = crsdr_plan_sync(p);
+        if (rc) return rc;
+        HIP_TRY(hipMemcpy(p->d_frac_override, frac_override, sizeof(float) * (size_t)p->nrows, hipMemcpyHostToDevice));
+    }
+    p->frac_apply = true; p->frac_gain = gain; p->frac_override_on = frac_override != nullptr;
     return CRSDR_OK;
 }
 
@@ -1154,9 +1233,26 @@ extern "C" int crsdr_plan_submit_batch(crsdr_plan *p, const void *rows, int mem_
     {
         hipEvent_t *pe = prof_pair(p, CRSDR_KERNEL_ALIGN_QUANT);
         if (pe) HIP_TRY(hipEventRecord(pe[0], S));
-        if (vec16) hipLaunchKernelGGL(k_align_quant<true>, dim3(1 + p->row_count, nblocks, chunks), dim3(kAlignThreads), 0, S, aa);
-        else hipLaunchKernelGGL(k_align_quant<false>, dim3(1 + p->row_count, nblocks, chunks), dim3(kAlignThreads), 0, S, aa);
+        const bool apply = p->frac_apply && p->longblock && aa.digital;
+        // with the fractional-delay correction on, the rows come from the apply pass below: here only header + readcnt + row 0
+        const unsigned gx = apply ? 1u : 1u + (unsigned)p->row_count;
+        if (vec16) hipLaunchKernelGGL(k_align_quant<true>, dim3(gx, nblocks, chunks), dim3(kAlignThreads), 0, S, aa);
+        else hipLaunchKernelGGL(k_align_quant<false>, dim3(gx, nblocks, chunks), dim3(kAlignThreads), 0, S, aa);
         HIP_TRY(hipGetLastError());
+        if (apply) {
+            // apply pass (crsdr_plan_set_frac_apply): int8 -> column FFTs -> row FFTs x H_row -> inverse -> inverse column FFTs -> int8
+            lb::LongTw tw{p->d_wc, p->d_wf, p->d_tw1, p->d_tw, (uint32_t)(p->B - 1)};
+            const int n1 = 1 << p->log2n1, l1 = p->log2n1;
+            int8_t *obase = p->d_slab ? p->d_slab : p->d_packet + p->matrix_off + (size_t)p->row_begin * (size_t)p->B;
+            for (int r0 = 0; r0 < p->row_count; r0 += p->long_chunk) {
+                const int cnt = std::min(p->long_chunk, p->row_count - r0);
+                float2 *Yc = p->d_Y + (size_t)r0 * (size_t)p->B;
+                x14p::RampArgs ra{o_lag, o_frac, p->frac_override_on ? p->d_frac_override : nullptr, p->d_phasor, p->d_k2tab, p->d_wc, p->d_wf, lb::FBITS, p->frac_gain, p->row_begin + r0, l1};
+                HIP_TRY(CRSDR_DISPATCH_N1(l1, (launch_long_fwd_cols<LG, false>(S, cnt, d_in, p->row_begin + r0, xor80, tw, Yc))));
+                HIP_TRY(launch_long_rows_ramp(S, n1, cnt, Yc, p->d_twA, p->d_twB, ra));
+                HIP_TRY(CRSDR_DISPATCH_N1(l1, (launch_long_out_cols<LG>(S, cnt, Yc, tw, obase + (size_t)r0 * (size_t)p->B))));
+            }
+        }
         if (pe) HIP_TRY(hipEventRecord(pe[1], S));
     }
     { int rc_ = pack_tails(p, S, nblocks, o_lag, o_mag, o_frac); if (rc_) return rc_; }

@@ -145,8 +145,12 @@ struct LongPartial {
     int idx;
 };
 
-template <int LOG2N1>
-__global__ __launch_bounds__(THREADS, 2) void k_long_inv_cols(const float2 *__restrict__ Z, LongTw tw, LongPartial *__restrict__ part)
+// OUTPUT (the apply pass of crsdr_plan_set_frac_apply): Z is the inverse row transform of a row's RESAMPLED spectrum; the
+// column transforms then yield its time samples, and instead of |.|^2 / argmax the first L of them (n1 < N1/2: the second
+// half is the zero pad the shift wrapped into) are quantised like cdsp::convto8bit (src/cdsp.cc:51-54) into the row at
+// out + blockIdx.y * B -- the cpacketize::write(complex<float>*) of src/cpacketizer.cc:158-172 for this mode.
+template <int LOG2N1, bool OUTPUT = false>
+__global__ __launch_bounds__(THREADS, 2) void k_long_inv_cols(const float2 *__restrict__ Z, LongTw tw, LongPartial *__restrict__ part, int8_t *__restrict__ out = nullptr)
 {
     constexpr int N1 = 1 << LOG2N1, LOG2C = LOG2TILE - LOG2N1, C = 1 << LOG2C;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -184,6 +188,18 @@ __global__ __launch_bounds__(THREADS, 2) void k_long_inv_cols(const float2 *__re
     }
     __syncthreads();
     col_fft<LOG2N1, +1>(T, tw.tw1, tid);
+    if constexpr (OUTPUT) {
+        int8_t *orow = out + (size_t)blockIdx.y * B;
+        for (int e = 2 * tid; e < TILE; e += 2 * THREADS) {          // column pairs: one 32-bit store = samples n, n + 1
+            const int j = e >> LOG2C, c = e & (C - 1), n1 = rev_n1<LOG2N1>(j);
+            if (n1 >= N1 / 2) continue;
+            const float4 y = *reinterpret_cast<const float4 *>(T + e);
+            const uint32_t w = (uint32_t)(uint8_t)f32_to_i8(y.x) | ((uint32_t)(uint8_t)f32_to_i8(y.y) << 8) |
+                               ((uint32_t)(uint8_t)f32_to_i8(y.z) << 16) | ((uint32_t)(uint8_t)f32_to_i8(y.w) << 24);
+            *reinterpret_cast<uint32_t *>(orow + 2 * ((size_t)n1 * N2 + (size_t)(tile * C + c))) = w;
+        }
+        return;
+    }
     float bm = -1.0f;
     int bi = 0x7fffffff;
     for (int e = tid; e < TILE; e += THREADS) {

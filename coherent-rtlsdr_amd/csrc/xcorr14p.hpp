@@ -343,11 +343,53 @@ __global__ __launch_bounds__(THREADS, 2) void k_ref_spectrum14p(const int8_t *__
 
 // ---- 16384-point row transforms on cf32 lines (stage B of the long-block path, longblock.hpp) ---------
 // Same three passes as K0 / K1 with a full (un-pruned) first radix-32 stage, cf32 in and out:
-//   IS_REF: forward, conj -> refspec [slot][group];   else: forward, x conj(ref), inverse, in place.
+//   IS_REF: forward, conj -> refspec [slot][group];   else: forward, x conj(ref), inverse, in place;
+//   RAMP (with !IS_REF): forward, x the row's own fractional-delay response instead of conj(ref), inverse, in place --
+//   the apply pass of crsdr_plan_set_frac_apply.  The response for frequency bin k = k1 + N1 k2 of row r is
+//       H[k] = p_r / B * exp(+2 pi i k_s (lag_r + D_r) / B),   k_s = k for k < B/2, k - B otherwise
+//   (a circular advance of the zero-padded row by lag + D samples: for |lag| <= L exactly the zero-filled shift of the
+//   digital mode plus a band-limited interpolation by D; the phasor rotation and the 1/B of the unnormalised transform
+//   pair ride along).  k lag / B is reduced mod 1 in integers, k_s D / B is small; v_sin / v_cos take revolutions.
+//   k2 of a junction register comes from a table made once per plan by transforming a one-hot line (k2tab).
 // grid (N1 lines, rows); line l of row r at Y + (r * gridDim.x + l) * 16384.
-template <bool IS_REF>
+// (cos, sin)(2 pi x) for |x| <= ~1: nearest half turn taken out, then odd / even polynomials on [-pi/2, pi/2]
+// (terms to theta^13 / theta^12: below 6e-8 absolute).  The hardware v_sin / v_cos are not accurate enough here: a 1e-5
+// error in the response moves visibly more int8 outputs across a rounding boundary than the FFT pair's own rounding.
+__device__ __forceinline__ c2 cis2pi(float x)
+{
+    const float q = rintf(2.0f * x);                       // half turns
+    const float th = 6.28318530717958647692f * fmaf(-0.5f, q, x);
+    const float t2 = th * th;
+    float sn = fmaf(t2, 1.6059043836821613e-10f, -2.5052108385441720e-08f);
+    sn = fmaf(t2, sn, 2.7557319223985893e-06f);
+    sn = fmaf(t2, sn, -1.9841269841269841e-04f);
+    sn = fmaf(t2, sn, 8.3333333333333332e-03f);
+    sn = fmaf(t2, sn, -1.6666666666666666e-01f);
+    sn = fmaf(th * t2, sn, th);
+    float cs = fmaf(t2, 2.0876756987868100e-09f, -2.7557319223985888e-07f);
+    cs = fmaf(t2, cs, 2.4801587301587302e-05f);
+    cs = fmaf(t2, cs, -1.3888888888888889e-03f);
+    cs = fmaf(t2, cs, 4.1666666666666664e-02f);
+    cs = fmaf(t2, cs, -0.5f);
+    cs = fmaf(t2, cs, 1.0f);
+    const float sg = ((int)q & 1) ? -1.0f : 1.0f;
+    return mk(sg * cs, sg * sn);
+}
+
+struct RampArgs {
+    const int32_t *lag;        // [nrows] this block's lag per row
+    const float *frac;         // [nrows] this block's parabolic estimate
+    const float *frac_override; // [nrows] caller-supplied fractional delays, or nullptr: gain * frac
+    const float2 *phasor;      // [nrows] get_phasecorrect() after this block
+    const uint32_t *k2tab;     // [8192]: k2 of the two complex values of refspec slot q, lo / hi 16 bits
+    const float2 *wc, *wf;     // two-level table of W_B^m (longblock.hpp LongTw): coarse W_B^(i << fbits), fine W_B^j
+    int fbits;
+    float gain;
+    int row0, log2n1;          // global row of blockIdx.y == 0
+};
+template <bool IS_REF, bool RAMP = false>
 __global__ __launch_bounds__(THREADS, 2) void k_rows14_cf32p(c2 *__restrict__ Y, const c2 *__restrict__ twA,
-                                                             const c2 *__restrict__ twB, float4 *__restrict__ refspec_base)
+                                                             const c2 *__restrict__ twB, float4 *__restrict__ refspec_base, RampArgs ra = RampArgs{})
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     c2 *A = reinterpret_cast<c2 *>(smem);
@@ -376,9 +418,37 @@ __global__ __launch_bounds__(THREADS, 2) void k_rows14_cf32p(c2 *__restrict__ Y,
     for (int h = 0; h < 2; ++h) {
         const int g = ((tid >> 6) << 7) + 64 * h + (tid & 63), base = j_base(g), key = g & 7;
         float4 r[8];
-        if constexpr (!IS_REF) {
+        if constexpr (!IS_REF && !RAMP) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) r[j] = refspec4[j * 1024 + g];
+        }
+        if constexpr (RAMP) {
+            const int row = ra.row0 + (int)blockIdx.y, log2B = 14 + ra.log2n1;
+            const uint32_t bmask = (1u << log2B) - 1u, lagu = (uint32_t)ra.lag[row];
+            const float invB = 1.0f / (float)(1u << log2B);
+            const float D = ra.frac_override ? ra.frac_override[row] : ra.gain * ra.frac[row];
+            const float2 pr = ra.phasor[row];
+            const c2 pb = mk(pr.x * invB, pr.y * invB);
+            const float dstep = D * invB;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const uint32_t kk = ra.k2tab[j * 1024 + g];
+                float hx[4];
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const uint32_t k2 = e ? (kk >> 16) : (kk & 0xffffu);
+                    const uint32_t k = (uint32_t)blockIdx.x + (k2 << ra.log2n1);
+                    const int ks = (k <= (bmask >> 1)) ? (int)k : (int)k - (int)(bmask + 1u);
+                    // integer part: exp(+2 pi i (k lag mod B) / B) = conj(W_B^m) from the plan's two-level table (one product, ~1 ulp);
+                    // fractional part: |k_s D / B| <= 1/4 turn, by polynomial
+                    const uint32_t m = (k * lagu) & bmask;
+                    const float2 a = ra.wc[m >> ra.fbits], f = ra.wf[m & ((1u << ra.fbits) - 1u)];
+                    const c2 wi = cmul(mk(a.x, a.y), mk(f.x, f.y));
+                    const c2 h = cmul(cmulc(pb, wi), cis2pi((float)ks * dstep));
+                    hx[2 * e] = h.x; hx[2 * e + 1] = h.y;
+                }
+                r[j] = make_float4(hx[0], hx[1], hx[2], hx[3]);
+            }
         }
         c2 u[16];
 #pragma unroll

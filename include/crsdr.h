@@ -200,6 +200,18 @@ int crsdr_plan_fetch(crsdr_plan *plan, int32_t *lag, float *mag, float *frac, fl
 int crsdr_plan_fetch_block(crsdr_plan *plan, int block, int32_t *lag, float *mag, float *frac, float *phasor,
                            int8_t *packet);
 
+/* Fractional-delay correction (BASELINE config 5 "long-block regime + fractional-delay phase correction"; SURVEY 8 note
+ * "Fractional delay": report D and, if applied, apply it as a linear phase ramp in the frequency domain).  The reference
+ * computes a 3-point estimate and discards it (src/ccoherent.cc:206-219); its authors' study of applying one
+ * (matlabclient/notes.m:9-40) finds a signal-dependent gain between estimate and true delay, hence `gain` / the override.
+ * Long-block plans (blocksize > 16384) in CRSDR_MODE_DIGITAL only; off by default (the reference-faithful behaviour).
+ * With it on, row k of the matrix is the row advanced by lag_k + D_k samples -- a circular advance of the zero-padded row in
+ * the frequency domain: X[f] * exp(+2 pi i f_s (lag_k + D_k) / B), f_s the signed bin index -- then rotated by the phasor
+ * and quantised like cdsp::convto8bit; for D = 0 that is the digital mode's zero-filled integer shift.
+ *   D_k = frac_override[k] if given (host [nrows], copied; entry 0 ignored), else gain * frac_k (this block's estimate).
+ * lag / mag / frac / phasor outputs are unchanged (the phase is still estimated on the integer-aligned row). */
+int crsdr_plan_set_frac_apply(crsdr_plan *plan, int enable, float gain, const float *frac_override);
+
 /* Block until everything submitted so far has finished (no copies). */
 int crsdr_plan_sync(crsdr_plan *plan);
 

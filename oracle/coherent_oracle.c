@@ -253,6 +253,10 @@ struct orc_engine {
     /* per-block shared */
     float *ref_f;   /* [B] crefsdr sfloat: zeros in [0,L), samples in [L,2L) src/crtlsdr.cc:215-218 */
     float *ref_fft; /* [B] sfft row 0 */
+    /* fractional-delay correction (orc_engine_set_frac_apply), off by default */
+    int frac_apply;
+    float frac_gain;
+    float *frac_override; /* [nrows] or NULL */
 };
 
 typedef struct {
@@ -315,8 +319,56 @@ void orc_engine_destroy(orc_engine *e)
     if (!e) return;
     twiddle_free(&e->tw);
     free(e->phasecorr); free(e->phasecorrprev); free(e->lag); free(e->mag); free(e->frac);
-    free(e->ref_f); free(e->ref_fft);
+    free(e->ref_f); free(e->ref_fft); free(e->frac_override);
     free(e);
+}
+
+int orc_engine_set_frac_apply(orc_engine *e, int enable, float gain, const float *frac_override)
+{
+    if (!e) return -1;
+    e->frac_apply = enable ? 1 : 0;
+    e->frac_gain = gain;
+    free(e->frac_override);
+    e->frac_override = NULL;
+    if (enable && frac_override) {
+        e->frac_override = (float *)malloc(sizeof(float) * (size_t)e->nrows);
+        if (!e->frac_override) return -1;
+        memcpy(e->frac_override, frac_override, sizeof(float) * (size_t)e->nrows);
+    }
+    return 0;
+}
+
+/* Fractional-delay correction of one row (SURVEY 8 note "Fractional delay": applied as a linear phase ramp in the
+ * frequency domain): the zero-padded row s (B complex) is advanced by delta = lag + D samples,
+ *     y = IFFT( FFT(s)[f] * exp(+2 pi i f_s delta / B) ) / B,   f_s = f for f < B/2, f - B otherwise,
+ * rotated by the row's phasor, and its first L samples are quantised (cdsp::convto8bit).  For D = 0 and |lag| <= L this
+ * is the zero-filled integer shift of the digital mode.  The ramp is formed in double and rounded once. */
+static void frac_apply_row(const orc_engine *e, orc_scratch *w, int row, int8_t *out)
+{
+    const int B = e->B, L = e->L;
+    const double D = e->frac_override ? (double)e->frac_override[row] : (double)(e->frac_gain * e->frac[row]);
+    const double delta = (double)e->lag[row] + D;
+    const float pr = e->phasecorr[2 * row], pi = e->phasecorr[2 * row + 1];
+    memcpy(w->c, w->s, sizeof(float) * 2 * (size_t)B);
+    fft_one(&e->tw, w->a, w->c, w->b, -1);
+    const float invB = 1.0f / (float)B;
+    for (int f = 0; f < B; f++) {
+        const int fs = f < B / 2 ? f : f - B;
+        /* reduce f_s * lag mod B in integers, keep the small f_s * D part in double */
+        const long long il = ((long long)fs * (long long)e->lag[row]) % (long long)B;
+        const double rev = (double)il / (double)B + (double)fs * D / (double)B;
+        const double ang = 2.0 * 3.14159265358979323846 * rev;
+        const float hr0 = (float)cos(ang), hi0 = (float)sin(ang);
+        /* h = (p / B) * e^{i ang} */
+        const float pbr = pr * invB, pbi = pi * invB;
+        const float hr = pbr * hr0 - pbi * hi0, hi = pbr * hi0 + pbi * hr0;
+        const float xr = w->a[2 * f], xi = w->a[2 * f + 1];
+        w->b[2 * f] = xr * hr - xi * hi;
+        w->b[2 * f + 1] = xr * hi + xi * hr;
+    }
+    (void)delta;
+    fft_one(&e->tw, w->c, w->b, w->a, +1);
+    orc_convto8bit(out, w->c, L);
 }
 
 /* ccoherent::computelag for one queued row (src/ccoherent.cc:154-239), row-at-a-time:
@@ -402,6 +454,11 @@ static void process_row(orc_engine *e, orc_scratch *w, int row, const int8_t *ro
         y = t;
     }
     if (refnoise_enabled) est_phasecorrect(e, row, y, e->ref_f + 2 * (size_t)L); /* :271-273 */
+    if (e->frac_apply && e->mode == ORC_MODE_DIGITAL) {
+        /* the matrix row comes from the frequency-domain resampling (shift + fractional delay + rotation in one) */
+        if (matrix) frac_apply_row(e, w, row, matrix + (size_t)row * B);
+        return;
+    }
     /* csdrdevice::phasecorrect src/csdrdevice.cc:80-84, applied every block (:275) */
     orc_scalarmul(y, y, e->phasecorr[2 * row], e->phasecorr[2 * row + 1], L);
     /* cpacketize::write(complex<float>*) src/cpacketizer.cc:158-172 */

@@ -89,6 +89,12 @@ int orc_engine_block(orc_engine *e, const int8_t *rows, const uint32_t *readcnt,
                      const uint8_t *lag_mask, int refnoise_enabled, uint32_t seq,
                      int32_t *lag, float *mag, float *frac, float *phasor, int8_t *packet);
 
+/* Fractional-delay correction of the matrix rows in ORC_MODE_DIGITAL (the build's crsdr_plan_set_frac_apply; the reference
+ * computes a fractional estimate and discards it, src/ccoherent.cc:206-219; matlabclient/notes.m:9-40 studies applying one):
+ * row k is advanced by lag_k + D_k samples through a linear phase ramp on its zero-padded spectrum, rotated by its phasor,
+ * quantised.  D_k = frac_override[k] if given ([nrows], copied), else gain * frac_k.  Off by default. */
+int orc_engine_set_frac_apply(orc_engine *e, int enable, float gain, const float *frac_override);
+
 size_t orc_packet_bytes(int nrows, int B);   /* 16 + 4*nrows + nrows*B */
 size_t orc_packet_matrix_offset(int nrows);  /* 16 + 4*nrows */
 

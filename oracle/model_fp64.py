@@ -53,6 +53,12 @@ class Model:
         self.mag = np.zeros(nrows)
         self.frac = np.zeros(nrows)
         self.raw = np.ones(nrows, dtype=np.complex128)    # un-averaged unit phasor of the last block
+        self.frac_apply, self.frac_gain, self.frac_override = False, 1.0, None
+
+    def set_frac_apply(self, enable=True, gain=1.0, frac_override=None):
+        """Fractional-delay correction of the matrix rows (the build's crsdr_plan_set_frac_apply), DIGITAL mode."""
+        self.frac_apply, self.frac_gain = bool(enable), float(gain)
+        self.frac_override = None if frac_override is None else np.asarray(frac_override, dtype=np.float64)
 
     def block(self, rows: np.ndarray, lag_mask=None, refnoise_enabled: bool = True):
         L = self.L
@@ -76,6 +82,13 @@ class Model:
                 if a != 0.0:
                     self.raw[r] = np.conj(corr) / a        # :63
                     self.p[r] = 0.5 * self.raw[r] + 0.5 * self.p[r]   # :66-67
+            if self.frac_apply and self.mode == DIGITAL:
+                # the zero-padded row advanced by lag + D samples: linear phase ramp over the SIGNED bin index
+                D = self.frac_override[r] if self.frac_override is not None else self.frac_gain * self.frac[r]
+                a = np.zeros(2 * L, dtype=np.complex128)
+                a[:L] = s
+                fs = np.fft.fftfreq(2 * L, d=1.0 / (2 * L))                   # 0 .. L-1, -L .. -1
+                y = np.fft.ifft(np.fft.fft(a) * np.exp(2j * np.pi * fs * (float(self.lag[r]) + D) / (2 * L)))[:L]
             z = y * self.p[r] * 127.0                      # :80-84 then src/cdsp.cc:51-54
             q = np.empty(2 * L)
             q[0::2], q[1::2] = z.real, z.imag

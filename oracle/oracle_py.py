@@ -48,6 +48,7 @@ def _declare(L):
     L.orc_engine_reset.argtypes = [C.c_void_p]
     L.orc_engine_block_mt.argtypes = [C.c_void_p, i8p, u32p, u8p, C.c_int, C.c_uint32,
                                       i32p, f32p, f32p, f32p, i8p, C.c_int]
+    L.orc_engine_set_frac_apply.argtypes = [C.c_void_p, C.c_int, C.c_float, f32p]
     L.orc_packet_bytes.argtypes = [C.c_int, C.c_int]
     L.orc_packet_bytes.restype = C.c_size_t
     L.orc_packet_matrix_offset.argtypes = [C.c_int]
@@ -200,6 +201,11 @@ class Engine:
 
     def reset(self):
         self._L.orc_engine_reset(self._h)
+
+    def set_frac_apply(self, enable=True, gain=1.0, frac_override=None):
+        ov = None if frac_override is None else np.ascontiguousarray(frac_override, dtype=np.float32)
+        if self._L.orc_engine_set_frac_apply(self._h, int(bool(enable)), C.c_float(gain), _p(ov, C.c_float)):
+            raise RuntimeError("orc_engine_set_frac_apply failed")
 
     def block(self, rows, readcnt=None, lag_mask=None, refnoise_enabled=True, seq=0, nthreads=1,
               want_packet=True):

@@ -1,0 +1,168 @@
+"""GPU: fractional-delay correction of the long-block path (BASELINE config 5: "long-block HBM-streaming regime +
+fractional-delay phase correction"; SURVEY 8 note "Fractional delay": reported as `frac` and, if applied, applied as a
+linear phase ramp in the frequency domain).  crsdr_plan_set_frac_apply is opt-in -- the reference computes a fractional
+estimate and discards it (src/ccoherent.cc:206-219) -- and is checked against the oracle and the fp64 model, which apply the
+same ramp, plus a known answer: a band-limited row delayed by a non-integer number of samples comes out aligned
+(correlation peak centred, no residual phase ramp across the band), which the integer shift alone cannot do.
+Bars: int8 matrix equal to the oracle / model except +-1 LSB at rounding boundaries (the two sides run different fp32 FFT
+factorisations; v_sin / v_cos against libm), lags and phasors as everywhere else."""
+import importlib
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def b():
+    binding = importlib.import_module("coherent-rtlsdr_amd.binding")
+    if binding.device_count() < 1:
+        pytest.fail("no HIP device: the product path has no CPU fallback")
+    return binding
+
+
+def _matrix_close(got, exp, frac_allowed):
+    d = got.astype(np.int16) - exp.astype(np.int16)
+    assert np.abs(d).max() <= 1
+    assert np.count_nonzero(d) <= frac_allowed * d.size, (np.count_nonzero(d), d.size)
+
+
+@pytest.mark.parametrize("log2B", [15, 16, 18])
+def test_frac_apply_matches_oracle_and_fp64_model(b, oracle, model, synth, log2B):
+    nsig, B = 4, 1 << log2B
+    L = B // 2
+    seed = 900 + log2B
+    params = synth.RowParams(nsig, L, seed)
+    D = np.array([0.0, 0.5, -0.25, 0.3, 0.0], dtype=np.float32)               # entry 0 (the reference row) is ignored
+    plan, orc, mod = b.Plan(nsig + 1, B, b.MODE_DIGITAL), oracle.Engine(nsig + 1, B, oracle.DIGITAL), model.Model(nsig + 1, B, model.DIGITAL)
+    for x in (plan, orc, mod):
+        x.set_frac_apply(True, 1.0, D)
+    for t in range(2):
+        rows, _ = synth.make_block(nsig, L, seed, t, params=params)
+        got, exp = plan.block(rows, seq=t), orc.block(rows, seq=t)
+        assert np.array_equal(got["lag"], exp["lag"]) and np.array_equal(got["lag"][1:], params.d)
+        assert np.abs(np.angle(got["phasor"][1:] * np.conj(exp["phasor"][1:]))).max() <= 1e-5
+        _matrix_close(got["matrix"], exp["matrix"], 2e-3)
+        _matrix_close(got["matrix"], mod.block(rows)[4], 2e-3)
+        assert np.array_equal(got["matrix"][0], rows[0])                       # raw reference row, header as ever
+        assert np.array_equal(got["packet"][:plan.matrix_offset], exp["packet"][:orc.matrix_offset])
+    # row 4 has D = 0: the frequency-domain path reproduces the integer shift of the digital mode (zero-filled) to rounding
+    plain = b.Plan(nsig + 1, B, b.MODE_DIGITAL)
+    for t in range(2):
+        rows, _ = synth.make_block(nsig, L, seed, t, params=params)
+        ref_out = plain.block(rows, seq=t)
+    _matrix_close(got["matrix"][4:5], ref_out["matrix"][4:5], 2e-3)
+    # estimate-driven (no override): D = gain * frac of the same block on both sides; the two frac estimates differ by ~1e-3
+    # of a sample, so a few more entries sit on the other side of a rounding boundary
+    plan.set_frac_apply(True, 2.0, None)
+    orc.set_frac_apply(True, 2.0, None)
+    rows, _ = synth.make_block(nsig, L, seed, 2, params=params)
+    got, exp = plan.block(rows, seq=2), orc.block(rows, seq=2)
+    assert np.allclose(got["frac"], exp["frac"], atol=5e-3)
+    _matrix_close(got["matrix"], exp["matrix"], 3e-2)
+    # and off again: back to the plain digital mode
+    plan.set_frac_apply(False)
+    rows, _ = synth.make_block(nsig, L, seed, 3, params=params)
+    got = plan.block(rows, seq=3)
+    exp = plain.block(rows, seq=3)
+    assert np.array_equal(got["lag"], exp["lag"])
+    plan.close(); plain.close()
+
+
+def _bandlimited_rows(L, total_delays, phis, seed=3, band=0.25, sigma=30.0):
+    """ref = low-pass complex Gaussian noise (|f| < band * fs / 2); row k = ref delayed by total_delays[k] samples
+    (any real number: the delay is a phase ramp on a 4L-point spectrum of a longer realisation, so nothing wraps into
+    the block) and rotated by phis[k]; int8, round half even."""
+    rng = np.random.default_rng(seed)
+    n = 4 * L
+    X = np.fft.fft(rng.standard_normal(n) + 1j * rng.standard_normal(n))
+    f = np.fft.fftfreq(n)
+    X[np.abs(f) > band / 2] = 0
+    base = np.fft.ifft(X)
+    base *= sigma / np.sqrt(np.mean(np.abs(base) ** 2) / 2)
+
+    def q(x):
+        out = np.empty(2 * L, dtype=np.int8)
+        out[0::2] = np.clip(np.rint(x.real), -128, 127)
+        out[1::2] = np.clip(np.rint(x.imag), -128, 127)
+        return out
+
+    rows = np.zeros((1 + len(total_delays), 2 * L), dtype=np.int8)
+    rows[0] = q(base[L:2 * L])
+    for k, (tau, phi) in enumerate(zip(total_delays, phis)):
+        xs = np.fft.ifft(X * np.exp(-2j * np.pi * f * tau)) * (sigma / np.sqrt(np.mean(np.abs(np.fft.ifft(X)) ** 2) / 2))
+        rows[1 + k] = q(xs[L:2 * L] * np.exp(1j * phi))
+    return rows
+
+
+def _residual_delay(y, r, band=0.25):
+    """slope of the cross-spectrum phase over the occupied band, in samples (0 = aligned)"""
+    n = y.size
+    win = np.hanning(n)
+    Y, R = np.fft.fft(y * win), np.fft.fft(r * win)
+    f = np.fft.fftfreq(n)
+    m = np.abs(f) < 0.8 * band / 2
+    c = Y[m] * np.conj(R[m])
+    ph = np.angle(c * np.exp(-1j * np.angle(np.sum(c))))
+    w = np.abs(c)
+    slope = np.sum(w * f[m] * ph) / np.sum(w * f[m] ** 2)      # phase = -2 pi f tau
+    return -slope / (2 * np.pi)
+
+
+def test_non_integer_delays_come_out_aligned_with_the_ramp_applied(b, model):
+    # known answer: rows delayed by d + delta samples (delta = +-0.5: the half-sample case, 0.25, -0.4).  The integer lag is
+    # whatever the correlation peak says (d or d + 1 for a half-sample delay); the caller supplies the remainder
+    # (matlabclient/notes.m:9-40: the parabolic estimate needs a signal-dependent calibration before it can be consumed).
+    L = 1 << 15
+    total = [37.5, -120.5, 300.25, -7.4]
+    phis = [0.4, -1.1, 2.5, 0.0]
+    rows = _bandlimited_rows(L, total, phis)
+    plan = b.Plan(5, 2 * L, b.MODE_DIGITAL)
+    out = plan.block(rows)
+    lag = out["lag"].astype(np.float64)
+    assert np.all(np.abs(lag[1:] - np.array(total)) <= 0.5 + 1e-9)              # the integer part, as reported
+    ref = model.to_complex(rows[0])
+    before = [_residual_delay(model.to_complex(out["matrix"][1 + k]), ref) for k in range(4)]
+    rem = np.zeros(5, dtype=np.float32)
+    rem[1:] = np.array(total) - lag[1:]
+    plan.set_frac_apply(True, 1.0, rem)
+    for t in range(8):                                                          # EMA phasor settles
+        out = plan.block(rows, seq=1 + t)
+    for k in range(4):
+        y = model.to_complex(out["matrix"][1 + k])
+        after = _residual_delay(y, ref)
+        assert abs(before[k] - rem[1 + k]) < 0.05, (k, before[k], rem[1 + k])   # the integer shift leaves the fraction in
+        assert abs(after) < 0.02, (k, after)                                     # the ramp takes it out
+        lg, _, fr, _ = model.xcorr_lag(y, ref)
+        assert lg == 0 and abs(fr) < 0.03, (k, lg, fr)                           # centred peak, symmetric neighbours
+        assert abs(np.angle(np.sum(y * np.conj(ref)))) < 0.03                    # and the phase is out as well
+    plan.close()
+
+
+def test_cfg5_full_size_with_fractional_delays(b, oracle, synth):
+    # BASELINE config 5 at full size: 1 + 21 rows x 2^20 samples, every row with its own fractional delay
+    nsig, L = 21, 1 << 20
+    seed = synth.config_seed(5)
+    params = synth.RowParams(nsig, L, seed)
+    rng = np.random.default_rng(5)
+    D = np.concatenate([[0.0], rng.uniform(-0.5, 0.5, nsig)]).astype(np.float32)
+    rows, _ = synth.make_block(nsig, L, seed, 0, params=params)
+    plan, orc = b.Plan(nsig + 1, 2 * L, b.MODE_DIGITAL), oracle.Engine(nsig + 1, 2 * L, oracle.DIGITAL)
+    plan.set_frac_apply(True, 1.0, D)
+    orc.set_frac_apply(True, 1.0, D)
+    got, exp = plan.block(rows), orc.block(rows, nthreads=8)
+    assert np.array_equal(got["lag"][1:], params.d)
+    _matrix_close(got["matrix"], exp["matrix"], 2e-3)
+    plan.close()
+
+
+def test_frac_apply_argument_checks(b):
+    short = b.Plan(3, 16384, b.MODE_DIGITAL)
+    with pytest.raises(b.CrsdrError):
+        short.set_frac_apply(True)                    # LDS-resident blocks: not offered (config 5 is the long-block regime)
+    short.set_frac_apply(False)                       # switching it off is always fine
+    faithful = b.Plan(3, 1 << 15, b.MODE_FAITHFUL)
+    with pytest.raises(b.CrsdrError):
+        faithful.set_frac_apply(True)                 # the faithful mode never shifts samples
+    short.close(); faithful.close()
