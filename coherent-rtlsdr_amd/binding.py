@@ -32,7 +32,7 @@ ABI_SYMBOLS = [
     "crsdr_noisesubspace", "crsdr_pmusic2d", "crsdr_plan_bind_slab", "crsdr_assemble_slabs",
     "crsdr_device_info", "crsdr_host_alloc", "crsdr_host_free",
     "crsdr_plan_bind_slab_ex", "crsdr_exchange_geometry", "crsdr_exchange_rooted_blocks", "crsdr_assemble_slots",
-    "crsdr_plan_set_frac_apply", "crsdr_exchange_unique_id", "crsdr_exchange_create", "crsdr_exchange_destroy", "crsdr_exchange_batch", "crsdr_exchange_schedule",
+    "crsdr_plan_set_frac_apply", "crsdr_plan_fetch_batch_async", "crsdr_plan_fetch_wait", "crsdr_exchange_unique_id", "crsdr_exchange_create", "crsdr_exchange_destroy", "crsdr_exchange_batch", "crsdr_exchange_schedule",
 ]
 XCHG_STAGED, XCHG_INPLACE = 0, 1
 EXCHANGE_ID_BYTES = 128
@@ -121,6 +121,8 @@ def lib():
     L.crsdr_plan_submit_batch.argtypes = [vp, vp, C.c_int, C.c_int, C.c_size_t, u32p, u8p, C.c_uint32, C.c_uint32]
     szp = C.POINTER(C.c_size_t)
     L.crsdr_plan_set_frac_apply.argtypes = [vp, C.c_int, C.c_float, f32p]
+    L.crsdr_plan_fetch_batch_async.argtypes = [vp, vp, vp, vp, vp, vp, C.c_size_t]
+    L.crsdr_plan_fetch_wait.argtypes = [vp]
     L.crsdr_plan_bind_slab_ex.argtypes = [vp, vp, C.c_size_t, C.c_int, C.c_int, C.c_size_t]
     L.crsdr_exchange_geometry.argtypes = [C.c_int, C.c_int, C.c_int, szp, szp, szp]
     L.crsdr_exchange_rooted_blocks.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
@@ -428,6 +430,14 @@ class Plan:
             self._keep.clear()
         return dict(lag=lag, mag=mag, frac=frac, phasor=ph.view(np.complex64), packet=pkt,
                     matrix=None if pkt is None else pkt[self.matrix_offset:].reshape(self.nrows, self.B))
+
+    def fetch_batch_async(self, lag=None, mag=None, frac=None, phasor=None, packets=None, host_packet_stride=0):
+        """crsdr_plan_fetch_batch_async: numpy views of page-locked memory (PinnedArray.array) or None"""
+        ptr = lambda a: C.c_void_p(a.ctypes.data) if a is not None else None
+        _check(lib().crsdr_plan_fetch_batch_async(self._h, ptr(lag), ptr(mag), ptr(frac), ptr(phasor), ptr(packets), int(host_packet_stride)))
+
+    def fetch_wait(self):
+        _check(lib().crsdr_plan_fetch_wait(self._h))
 
     def block(self, rows, **kw):
         self.submit(rows, **kw)

@@ -6,6 +6,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <cctype>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -15,6 +16,7 @@
 #include <mutex>
 #include <new>
 #include <vector>
+#include <sched.h>
 
 using namespace crsdr;
 
@@ -71,12 +73,54 @@ extern "C" int crsdr_device_info(int device, char *name, int name_cap, int *comp
 }
 
 static int require_device();
+// Page-locked memory should sit on the NUMA node the GPU hangs off: a transfer that crosses the socket interconnect runs at
+// roughly half the PCIe rate.  The pages are placed where the allocating thread runs, so the thread is moved to that node's
+// CPUs for the duration of the allocation (sysfs: /sys/bus/pci/devices/<bdf>/numa_node, /sys/devices/system/node/nodeN/cpulist).
+// Best effort: any failure leaves the affinity alone.  CRSDR_HOST_NUMA=0 switches it off.
+static bool near_device_cpus(cpu_set_t *set)
+{
+    static const bool enabled = [] { const char *e = getenv("CRSDR_HOST_NUMA"); return !e || atoi(e) != 0; }();
+    if (!enabled) return false;
+    int dev = 0;
+    char bdf[64] = {0}, path[256], buf[4096];
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetPCIBusId(bdf, sizeof(bdf), dev) != hipSuccess) return false;
+    for (char *c = bdf; *c; ++c) *c = (char)tolower(*c);
+    snprintf(path, sizeof(path), "/sys/bus/pci/devices/%s/numa_node", bdf);
+    FILE *f = fopen(path, "r");
+    if (!f) return false;
+    int node = -1;
+    const int got = fscanf(f, "%d", &node);
+    fclose(f);
+    if (got != 1 || node < 0) return false;
+    snprintf(path, sizeof(path), "/sys/devices/system/node/node%d/cpulist", node);
+    f = fopen(path, "r");
+    if (!f) return false;
+    const bool ok = fgets(buf, sizeof(buf), f) != nullptr;
+    fclose(f);
+    if (!ok) return false;
+    CPU_ZERO(set);
+    int n = 0;
+    for (char *tok = strtok(buf, ",\n"); tok; tok = strtok(nullptr, ",\n")) {
+        int lo = 0, hi = 0;
+        const int k = sscanf(tok, "%d-%d", &lo, &hi);
+        if (k < 1) continue;
+        if (k == 1) hi = lo;
+        for (int c = lo; c <= hi && c < CPU_SETSIZE; ++c) { CPU_SET(c, set); ++n; }
+    }
+    return n > 0;
+}
+
 extern "C" int crsdr_host_alloc(void **ptr, size_t bytes)
 {
     if (!ptr || !bytes) return fail(CRSDR_EINVAL, "host_alloc: NULL pointer or zero size");
     *ptr = nullptr;
     { int rc_ = require_device(); if (rc_) return rc_; }
+    cpu_set_t old_set, near_set;
+    const bool moved = sched_getaffinity(0, sizeof(old_set), &old_set) == 0 && near_device_cpus(&near_set) &&
+                       sched_setaffinity(0, sizeof(near_set), &near_set) == 0;
     hipError_t e = hipHostMalloc(ptr, bytes, hipHostMallocDefault);
+    if (e == hipSuccess && moved) memset(*ptr, 0, bytes);      // first touch on the near node, if the runtime left any page untouched
+    if (moved) (void)sched_setaffinity(0, sizeof(old_set), &old_set);
     if (e != hipSuccess) { *ptr = nullptr; return fail(e == hipErrorOutOfMemory ? CRSDR_ENOMEM : CRSDR_EHIP, "hipHostMalloc(%zu): %s", bytes, hipGetErrorString(e)); }
     return CRSDR_OK;
 }
@@ -621,6 +665,10 @@ struct crsdr_plan {
     // K1 on its own stream beside the phase kernel of the previous batch (see crsdr_plan_submit_batch): per-batch
     // {lag, mag, frac} are double-buffered (obuf), ev_k2done[i] = the phase kernel that read buffer i has finished
     hipStream_t xs = nullptr;
+    hipStream_t cs = nullptr;                       // copy stream of crsdr_plan_fetch_batch_async
+    hipEvent_t ev_copydone[4] = {nullptr, nullptr, nullptr, nullptr};   // one per outstanding asynchronous fetch (ring)
+    unsigned long copy_head = 0, copy_tail = 0;      // fetches waited for / issued
+    bool copy_pending = false;                       // the next submit's kernels wait for the newest of them
     hipEvent_t ev_k2done[2] = {nullptr, nullptr};
     bool k2done_valid[2] = {false, false};
     int obuf = 0;
@@ -752,6 +800,8 @@ static int plan_alloc(crsdr_plan *p)
     HIP_TRY(hipStreamCreateWithFlags(&p->own_stream, hipStreamNonBlocking));
     HIP_TRY(hipStreamCreateWithFlags(&p->aux, hipStreamNonBlocking));
     HIP_TRY(hipStreamCreateWithFlags(&p->xs, hipStreamNonBlocking));
+    HIP_TRY(hipStreamCreateWithFlags(&p->cs, hipStreamNonBlocking));
+    for (auto &e : p->ev_copydone) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     { const char *e = getenv("CRSDR_OVERLAP"); if (e) p->overlap = atoi(e) != 0; }
     p->stream = p->own_stream;
     hipEvent_t *evs[] = {&p->ev_fork, &p->ev_ref[0], &p->ev_ref[1], &p->ev_k1done[0], &p->ev_k1done[1], &p->ev_k2done[0], &p->ev_k2done[1]};
@@ -823,6 +873,8 @@ static void plan_free(crsdr_plan *p)
     if (p->own_stream) (void)hipStreamSynchronize(p->own_stream);
     if (p->aux) (void)hipStreamSynchronize(p->aux);
     if (p->xs) (void)hipStreamSynchronize(p->xs);
+    if (p->cs) { (void)hipStreamSynchronize(p->cs); (void)hipStreamDestroy(p->cs); }
+    for (auto e : p->ev_copydone) if (e) (void)hipEventDestroy(e);
     void *bufs[] = {p->d_frac_override, p->d_k2tab, p->d_wc, p->d_wf, p->d_tw1, p->d_Y, p->d_Yref, p->d_part, p->d_tw, p->d_twA, p->d_twB, p->d_refspec[0], p->d_refspec[1], p->d_rows, p->d_packet_alloc, p->d_readcnt,
                     p->d_mask, p->d_lag, p->d_mag, p->d_frac, p->d_phasor, p->d_corr, p->d_sync, p->d_state, p->d_state_snap};
     for (void *b : bufs) if (b) (void)hipFree(b);
@@ -888,6 +940,9 @@ extern "C" int crsdr_plan_sync(crsdr_plan *p)
     HIP_TRY(hipStreamSynchronize(p->stream));
     HIP_TRY(hipStreamSynchronize(p->aux));
     HIP_TRY(hipStreamSynchronize(p->xs));
+    HIP_TRY(hipStreamSynchronize(p->cs));
+    p->copy_pending = false;
+    p->copy_head = p->copy_tail;
     return check_fused_status(p);
 }
 
@@ -1054,6 +1109,14 @@ extern "C" int crsdr_plan_submit_batch(crsdr_plan *p, const void *rows, int mem_
         p->stage_valid[ss] = true;
     }
 
+    if (p->copy_pending) {
+        // a pipelined fetch of the previous batch is (or was) in flight: this batch's kernels overwrite what it reads.  The
+        // input copies above stay ahead of this wait, so they share the link with the device-to-host copies
+        hipEvent_t newest = p->ev_copydone[(p->copy_tail - 1) % 4];
+        HIP_TRY(hipStreamWaitEvent(S, newest, 0));
+        if (p->overlap) HIP_TRY(hipStreamWaitEvent(p->xs, newest, 0));
+        p->copy_pending = false;
+    }
     if (p->prof_slots) {
         const int ps = (int)(p->prof_count % p->prof_slots);
         for (int k = 0; k < kProfKernels; ++k) p->prof_has[(size_t)ps * kProfKernels + k] = 0;
@@ -1286,7 +1349,7 @@ static int check_fused_status(crsdr_plan *p)
             // lag / mag / frac and EMA phase state.  Restore the snapshot taken before the first of them, re-arm the
             // phase kernel's hand-over words, and keep this plan on the packed kernel from here on -- the caller
             // resubmits those batches and gets what an undisturbed run would have given.
-            (void)hipStreamSynchronize(p->stream); (void)hipStreamSynchronize(p->aux); (void)hipStreamSynchronize(p->xs);
+            (void)hipStreamSynchronize(p->stream); (void)hipStreamSynchronize(p->aux); (void)hipStreamSynchronize(p->xs); (void)hipStreamSynchronize(p->cs);
             (void)hipMemset(p->d_sync, 0, 64);                    // flags and the work counter (its count is off after a failed launch)
             p->q_work_base = 0;
             if (p->snap_valid) {
@@ -1328,6 +1391,51 @@ extern "C" int crsdr_plan_fetch_block(crsdr_plan *p, int block, int32_t *lag, fl
     if (frac) HIP_TRY(hipMemcpy(frac, p->d_frac + ob, sizeof(float) * n, hipMemcpyDeviceToHost));
     if (phasor) HIP_TRY(hipMemcpy(phasor, p->d_phasor + o, sizeof(float2) * n, hipMemcpyDeviceToHost));
     if (packet) HIP_TRY(hipMemcpy(packet, p->d_packet + (size_t)block * p->packet_stride, p->packet_bytes, hipMemcpyDeviceToHost));
+    return CRSDR_OK;
+}
+
+extern "C" int crsdr_plan_fetch_batch_async(crsdr_plan *p, int32_t *lag, float *mag, float *frac, float *phasor, int8_t *packets,
+                                            size_t host_packet_stride)
+{
+    if (!p) return fail(CRSDR_EINVAL, "plan_fetch_batch_async: NULL plan");
+    if (!p->submitted) return fail(CRSDR_ESTATE, "plan_fetch_batch_async: nothing submitted");
+    if (packets && p->d_slab) return fail(CRSDR_ESTATE, "plan_fetch_batch_async: slab output is bound, packets are assembled by the caller");
+    if (packets && host_packet_stride < p->packet_bytes) return fail(CRSDR_EINVAL, "plan_fetch_batch_async: host_packet_stride smaller than a packet");
+    if (p->copy_tail - p->copy_head >= 4) return fail(CRSDR_ESTATE, "plan_fetch_batch_async: four fetches outstanding, call crsdr_plan_fetch_wait first");
+    HIP_TRY(hipSetDevice(p->device));
+    const size_t n = (size_t)p->nrows, T = (size_t)p->last_nblocks;
+    const size_t ob = (size_t)p->obuf * n * (size_t)p->max_batch;
+    HIP_TRY(hipStreamWaitEvent(p->cs, p->ev_k2done[p->obuf], 0));          // the batch's last kernel
+    if (lag) HIP_TRY(hipMemcpyAsync(lag, p->d_lag + ob, sizeof(int32_t) * n * T, hipMemcpyDeviceToHost, p->cs));
+    if (mag) HIP_TRY(hipMemcpyAsync(mag, p->d_mag + ob, sizeof(float) * n * T, hipMemcpyDeviceToHost, p->cs));
+    if (frac) HIP_TRY(hipMemcpyAsync(frac, p->d_frac + ob, sizeof(float) * n * T, hipMemcpyDeviceToHost, p->cs));
+    if (phasor) HIP_TRY(hipMemcpyAsync(phasor, p->d_phasor, sizeof(float2) * n * T, hipMemcpyDeviceToHost, p->cs));
+    if (packets) {
+        if (host_packet_stride == p->packet_stride)
+            HIP_TRY(hipMemcpyAsync(packets, p->d_packet, p->packet_stride * (T - 1) + p->packet_bytes, hipMemcpyDeviceToHost, p->cs));
+        else
+            for (size_t t = 0; t < T; ++t)
+                HIP_TRY(hipMemcpyAsync(packets + t * host_packet_stride, p->d_packet + t * p->packet_stride, p->packet_bytes, hipMemcpyDeviceToHost, p->cs));
+    }
+    HIP_TRY(hipEventRecord(p->ev_copydone[p->copy_tail % 4], p->cs));
+    p->copy_tail++;
+    p->copy_pending = true;
+    return CRSDR_OK;
+}
+
+extern "C" int crsdr_plan_fetch_wait(crsdr_plan *p)
+{
+    if (!p) return fail(CRSDR_EINVAL, "plan_fetch_wait: NULL plan");
+    HIP_TRY(hipSetDevice(p->device));
+    if (p->copy_head == p->copy_tail) return fail(CRSDR_ESTATE, "plan_fetch_wait: no asynchronous fetch outstanding");
+    HIP_TRY(hipEventSynchronize(p->ev_copydone[p->copy_head % 4]));      // the OLDEST outstanding fetch: later ones keep flying
+    p->copy_head++;
+    // the kernels of that batch have finished (its copies followed them): their status words are final
+    if (p->k1_used) {
+        int w = 0;
+        HIP_TRY(hipMemcpy(&w, p->d_sync + 2, sizeof(w), hipMemcpyDeviceToHost));
+        if (w) return crsdr_plan_sync(p);                                  // drains everything, rolls back, reports
+    }
     return CRSDR_OK;
 }
 

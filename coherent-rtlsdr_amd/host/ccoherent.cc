@@ -3,7 +3,7 @@
 #include <cstdio>
 #include <cstring>
 
-ccoherent::ccoherent(crefsdr *refdev_, lvector<csdrdevice *> *devvec_, crefnoise *refnoise_, int nfft_, int mode_)
+ccoherent::ccoherent(crefsdr *refdev_, lvector<csdrdevice *> *devvec_, crefnoise *refnoise_, int nfft_, int mode_, int batch_)
     : devices(devvec_), refdev(refdev_), refnoise(refnoise_), nfft(nfft_), mode(mode_), plan(nullptr), rows(nullptr), packet(nullptr), packet_bytes(0), seq(0), do_exit(false)
 {
     blocksize = (int)refdev->get_blocksize();                 // src/ccoherent.cc:43
@@ -11,6 +11,8 @@ ccoherent::ccoherent(crefsdr *refdev_, lvector<csdrdevice *> *devvec_, crefnoise
     crsdr_plan_desc d;
     std::memset(&d, 0, sizeof(d));
     d.nrows = nrows; d.blocksize = blocksize; d.mode = mode; d.device = 0;
+    d.max_batch = batch_ > 1 ? batch_ : 1;
+    batch = d.max_batch;
     if (crsdr_plan_create(&plan, &d) != CRSDR_OK) {
         // same convention as the reference's backend-init failure (src/ccoherent.cc:54-61): print and continue
         std::fprintf(stderr, "ccoherent: %s\n", crsdr_last_error());
@@ -35,6 +37,76 @@ ccoherent::~ccoherent()
     if (plan) crsdr_plan_destroy(plan);
     crsdr_host_free(rows);
     crsdr_host_free(packet);
+    for (int i = 0; i < 2; ++i) {
+        crsdr_host_free(brows[i]); crsdr_host_free(bpackets[i]); crsdr_host_free(blag[i]);
+        crsdr_host_free(bmag[i]); crsdr_host_free(bfrac[i]); crsdr_host_free(bphasor[i]);
+    }
+}
+
+bool ccoherent::enable_batching(int T)
+{
+    if (!plan || T < 1 || T > batch) return false;
+    if (brows[0]) return true;
+    bstride = crsdr_plan_packet_stride(plan);
+    const size_t n = (size_t)nrows, Tz = (size_t)batch;
+    for (int i = 0; i < 2; ++i) {
+        if (crsdr_host_alloc((void **)&brows[i], Tz * n * (size_t)blocksize) != CRSDR_OK ||
+            crsdr_host_alloc((void **)&bpackets[i], Tz * bstride) != CRSDR_OK ||
+            crsdr_host_alloc((void **)&blag[i], Tz * n * sizeof(int32_t)) != CRSDR_OK ||
+            crsdr_host_alloc((void **)&bmag[i], Tz * n * sizeof(float)) != CRSDR_OK ||
+            crsdr_host_alloc((void **)&bfrac[i], Tz * n * sizeof(float)) != CRSDR_OK ||
+            crsdr_host_alloc((void **)&bphasor[i], Tz * n * 2 * sizeof(float)) != CRSDR_OK) {
+            std::fprintf(stderr, "ccoherent: %s\n", crsdr_last_error());
+            return false;
+        }
+    }
+    return true;
+}
+
+bool ccoherent::fill_batch(int slot, int nblocks)
+{
+    // the gather of step() (src/ccoherent.cc:250-283), nblocks times into one page-locked slot
+    for (int t = 0; t < nblocks; ++t) {
+        int8_t *dst = brows[slot] + (size_t)t * nrows * blocksize;
+        std::memcpy(dst, refdev->read(), blocksize);
+        refdev->consume();
+        int c = 1;
+        for (auto *d : *devices) {
+            std::memcpy(dst + (size_t)c * blocksize, d->read(), blocksize);
+            d->consume();
+            ++c;
+        }
+    }
+    return true;
+}
+
+bool ccoherent::submit_batch(int slot, int nblocks, uint32_t flags)
+{
+    if (!plan || !brows[0] || nblocks < 1 || nblocks > batch) return false;
+    // H2D of this batch shares the link with the D2H of the previous one (crsdr_plan_fetch_batch_async); its kernels queue behind both
+    if (crsdr_plan_submit_batch(plan, brows[slot], CRSDR_MEM_HOST, nblocks, 0, nullptr, nullptr, seq, flags) != CRSDR_OK ||
+        crsdr_plan_fetch_batch_async(plan, blag[slot], bmag[slot], bfrac[slot], bphasor[slot], bpackets[slot], bstride) != CRSDR_OK) {
+        std::fprintf(stderr, "ccoherent: %s\n", crsdr_last_error());
+        return false;
+    }
+    seq += (uint32_t)nblocks;
+    bcount[slot] = nblocks;
+    return true;
+}
+
+bool ccoherent::collect_batch(int slot)
+{
+    if (!plan || bcount[slot] < 1) return false;
+    if (crsdr_plan_fetch_wait(plan) != CRSDR_OK) { std::fprintf(stderr, "ccoherent: %s\n", crsdr_last_error()); return false; }
+    // (fetch_wait waits for the oldest outstanding fetch only: the batch submitted after this one keeps flying)
+    const int t = bcount[slot] - 1;                            // what get_lagp() / get_phasecorrect() show afterwards: the last block
+    int c = 1;
+    for (auto *d : *devices) {
+        d->set_lag((float)batch_lag(slot, t)[c], bmag[slot][(size_t)t * nrows + c]);          // src/ccoherent.cc:232-233
+        d->set_phasecorrect(std::complex<float>(batch_phasor(slot, t)[2 * c], batch_phasor(slot, t)[2 * c + 1]));
+        ++c;
+    }
+    return true;
 }
 
 void ccoherent::clearlagqueue() { lagqueue.clear(); }

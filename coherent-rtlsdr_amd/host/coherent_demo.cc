@@ -3,6 +3,7 @@
 // Exit code 0 iff every lag equals its injected delay and, in digital mode, the EMA phasors
 // converge to exp(-j phi_k).  --dump writes the first generated block for the csynth/synth.py
 // bit-exactness test; --cdsp runs a few class-cdsp identities through the per-op ABI.
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -50,7 +51,8 @@ int main(int argc, char **argv)
 {
     int nsig = 3, L = 8192, blocks = 12, mode = CRSDR_MODE_DIGITAL, dmax = -1;
     std::string dump, zmqaddr;
-    bool run_cdsp = false, servo = false, threads = false, music = false, servo_table = false;
+    bool run_cdsp = false, servo = false, threads = false, music = false, servo_table = false, bench = false;
+    int batch = 16;
     std::vector<double> table_lags;
     int table_fs = 2048000;
     std::string replay;
@@ -73,6 +75,8 @@ int main(int argc, char **argv)
         else if (a == "--replay" && i + 1 < argc) { replay = argv[++i]; threads = true; }   // <prefix><row>.u8: raw uint8 IQ recordings (f2)
         else if (a == "--music") music = true;      // f4: the last packet through the beamformer chain (needs nsig = 7 x 3)
         else if (a == "--fs") val(table_fs);
+        else if (a == "--bench") bench = true;      // pipelined batched engine over PCIe: blocks/s from C++, no Python in the loop
+        else if (a == "--batch") val(batch);
         else if (a == "--servo-table" && i + 1 < argc) {      // comma-separated lags
             servo_table = true;
             for (char *tok = std::strtok(argv[++i], ","); tok; tok = std::strtok(nullptr, ",")) table_lags.push_back(std::atof(tok));
@@ -109,7 +113,50 @@ int main(int argc, char **argv)
         last_seq = h->globalseqn; last_N = h->N; last_L = h->L; last_bytes = bytes; ++packets;
         if (music) last_packet.assign(p, p + bytes);
     };
-    ccoherent coherent(&ref, &devs, &refnoise, 8, mode);
+    ccoherent coherent(&ref, &devs, &refnoise, 8, mode, bench ? batch : 1);
+
+    if (bench) {
+        // The engine a batch at a time, pipelined: page-locked slots of `batch` blocks go over PCIe while the previous batch's
+        // packets come back (crsdr_plan_submit_batch + crsdr_plan_fetch_batch_async; src/ccoherent.cc:245-294 is the per-block
+        // loop this replaces).  Host rows in, host packets out for EVERY block -- the PCIe-inclusive rate, bounded by
+        // (1 + nsig) * B bytes each way per block.  The synthetic source is far slower than the link, so four distinct blocks
+        // are generated once and cycled through the slots; the transfers and the device work are the real ones.
+        if (!coherent.enable_batching(batch)) { std::printf("bench: batching unavailable\nDEMO FAILED\n"); return 1; }
+        const size_t blk = (size_t)(1 + nsig) * B;
+        std::vector<int8_t> distinct(4 * blk);
+        for (int t = 0; t < 4; ++t) { source.advance(); std::memcpy(distinct.data() + t * blk, source.row(0), blk); }
+        for (int sl = 0; sl < 2; ++sl)
+            for (int t = 0; t < batch; ++t) std::memcpy(coherent.batch_rows(sl) + (size_t)t * blk, distinct.data() + (size_t)((sl * batch + t) % 4) * blk, blk);
+        const int nb = std::max(3, blocks / batch);
+        const uint32_t fl = CRSDR_REFNOISE_ENABLED;
+        bool ok = true;
+        auto run = [&](int n) {
+            ok = ok && coherent.submit_batch(0, batch, fl);
+            for (int b = 1; b < n && ok; ++b) {
+                ok = ok && coherent.submit_batch(b & 1, batch, fl);       // upload of batch b overlaps the download of batch b - 1
+                ok = ok && coherent.collect_batch((b - 1) & 1);
+            }
+            ok = ok && coherent.collect_batch((n - 1) & 1);
+        };
+        run(3);                                                           // warm-up: allocations, code objects, link
+        const auto t0 = std::chrono::steady_clock::now();
+        run(nb);
+        const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        if (!ok) { std::printf("bench: engine error\nDEMO FAILED\n"); return 1; }
+        const csynth_params *p = source.get_params();
+        const int last = (nb - 1) & 1;
+        int bad = 0;
+        for (int t = 0; t < batch; ++t)
+            for (int k = 0; k < nsig; ++k) bad += (coherent.batch_lag(last, t)[1 + k] != (int32_t)p->d[k]);
+        const hdr0 *h = reinterpret_cast<const hdr0 *>(coherent.batch_packet(last, batch - 1));
+        bad += (h->N != (uint32_t)(1 + nsig)) + (h->L != (uint32_t)L);
+        const double bps = (double)nb * batch / dt, gbs = bps * (double)blk / 1e9;
+        std::printf("bench: %d batches x %d blocks of (1 + %d) x %d in %.3f s: %.1f blocks/s, %.2f GB/s each way over PCIe, lags %s\n", nb, batch, nsig, L, dt,
+                    bps, gbs, bad ? "MISMATCH" : "ok");
+        cpacketize::cleanup();
+        std::printf("%s\n", bad ? "DEMO FAILED" : "DEMO OK");
+        return bad ? 1 : 0;
+    }
 
     if (threads) {
         // f2: every device streams from its own producer thread into a ring (crtlsdr::asynch_threadf /

@@ -212,6 +212,19 @@ int crsdr_plan_fetch_block(crsdr_plan *plan, int block, int32_t *lag, float *mag
  * lag / mag / frac / phasor outputs are unchanged (the phase is still estimated on the integer-aligned row). */
 int crsdr_plan_set_frac_apply(crsdr_plan *plan, int enable, float gain, const float *frac_override);
 
+/* Pipelined fetch of the LAST submitted batch into page-locked host memory (crsdr_host_alloc): the device-to-host copies
+ * run on the plan's copy stream as soon as the batch's kernels have finished -- while the NEXT submit's host-to-device copies
+ * use the other direction of the link; the next submit's kernels wait on the device for these copies, so the plan's output
+ * buffers are never overwritten under them.  The host engine's loop (src/ccoherent.cc:245-294 run a batch at a time):
+ *     submit_batch(b) ; fetch_batch_async(b) ; submit_batch(b+1) ; fetch_batch_async(b+1) ; fetch_wait() -> batch b has landed ; ...
+ * Any pointer may be NULL.  lag / mag / frac: [nblocks][nrows]; phasor [nblocks][nrows][2]; packets: the batch's nblocks
+ * packets, packet t at packets + t * host_packet_stride (>= crsdr_plan_packet_bytes).  Pageable destinations work but
+ * serialise.  crsdr_plan_fetch_wait blocks until the OLDEST outstanding asynchronous fetch has landed (at most four may be
+ * outstanding; later ones keep flying) and reports a kernel-side error like crsdr_plan_fetch does. */
+int crsdr_plan_fetch_batch_async(crsdr_plan *plan, int32_t *lag, float *mag, float *frac, float *phasor, int8_t *packets,
+                                 size_t host_packet_stride);
+int crsdr_plan_fetch_wait(crsdr_plan *plan);
+
 /* Block until everything submitted so far has finished (no copies). */
 int crsdr_plan_sync(crsdr_plan *plan);
 

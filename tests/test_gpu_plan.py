@@ -240,6 +240,55 @@ def test_batched_submit_equals_blockwise(b, oracle, synth, mode):
     one.close(); many.close()
 
 
+def test_pipelined_async_fetch_equals_blockwise(b, synth):
+    # crsdr_plan_fetch_batch_async / crsdr_plan_fetch_wait: batches submitted back to back with their fetches in flight (the
+    # next submit's upload shares the link with the previous batch's download; its kernels wait on the device for that
+    # download) must hand back, batch by batch, exactly what fetching every block synchronously gives -- packets and scalars.
+    nsig, L, T, nb = 40, 8192, 6, 5
+    nrows, B = nsig + 1, 2 * L
+    params = synth.RowParams(nsig, L, 606, dmax=900)
+    blocks = np.stack([synth.make_block(nsig, L, 606, t, params=params)[0] for t in range(nb * T)])
+    ref = b.Plan(nrows, B, b.MODE_DIGITAL, max_batch=T)
+    exp = []
+    for i in range(nb):
+        ref.submit(blocks[i * T:(i + 1) * T], seq=i * T)
+        exp.append([ref.fetch(block=t) for t in range(T)])
+    plan = b.Plan(nrows, B, b.MODE_DIGITAL, max_batch=T)
+    pstride = plan.packet_stride
+    rows_pin = [b.PinnedArray((T, nrows, B), np.int8) for _ in range(2)]
+    out = [dict(lag=b.PinnedArray((T, nrows), np.int32), mag=b.PinnedArray((T, nrows), np.float32), frac=b.PinnedArray((T, nrows), np.float32),
+                phasor=b.PinnedArray((T, nrows, 2), np.float32), packets=b.PinnedArray((T * pstride,), np.int8)) for _ in range(2)]
+
+    def submit(i):
+        s = i & 1
+        rows_pin[s].array[:] = blocks[i * T:(i + 1) * T]
+        plan.submit(rows_pin[s].array, seq=i * T)
+        o = out[s]
+        plan.fetch_batch_async(o["lag"].array, o["mag"].array, o["frac"].array, o["phasor"].array, o["packets"].array, pstride)
+
+    def check(i):
+        plan.fetch_wait()
+        o = out[i & 1]
+        for t in range(T):
+            e = exp[i][t]
+            assert np.array_equal(o["lag"].array[t], e["lag"]) and np.array_equal(o["mag"].array[t], e["mag"]), (i, t)
+            assert np.array_equal(o["frac"].array[t], e["frac"]), (i, t)
+            assert np.array_equal(o["phasor"].array[t].reshape(-1).view(np.complex64), e["phasor"]), (i, t)
+            assert np.array_equal(o["packets"].array[t * pstride: t * pstride + plan.packet_bytes], e["packet"]), (i, t)
+
+    submit(0)
+    for i in range(1, nb):
+        submit(i)
+        check(i - 1)
+    check(nb - 1)
+    with pytest.raises(b.CrsdrError):
+        plan.fetch_wait()                                        # nothing outstanding any more
+    plan.sync()
+    for x in rows_pin + [v for o in out for v in o.values()]:
+        x.close()
+    plan.close(); ref.close()
+
+
 def test_batch_argument_checks(b):
     plan = b.Plan(3, 1024, max_batch=2)
     with pytest.raises(b.CrsdrError):

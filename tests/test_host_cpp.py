@@ -133,6 +133,19 @@ def test_host_demo_beamformer_chain_sees_the_aligned_noise_at_broadside(host_bui
 
 
 @pytest.mark.gpu
+def test_pipelined_cpp_engine_bench(host_build):
+    # the batched engine from C++ (ccoherent::submit_batch / collect_batch over crsdr_plan_submit_batch +
+    # crsdr_plan_fetch_batch_async): host rows in, host packets out for every block, upload of batch b + 1 under the download
+    # of batch b; lags of the last batch checked against the injected delays by the demo itself
+    r = subprocess.run([os.path.join(host_build, "coherent_demo"), "--bench", "--nsig", "128", "--batch", "8", "--blocks", "96"],
+                       capture_output=True, text=True, timeout=300)
+    print(r.stdout, r.stderr)
+    assert r.returncode == 0 and "DEMO OK" in r.stdout, r.stdout + r.stderr
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("bench:")][0]
+    assert float(line.split("s: ")[1].split(" blocks/s")[0]) > 1000.0       # 129 rows: far above the 1025-row link bound
+
+
+@pytest.mark.gpu
 def test_servo_model_drives_track_to_locked(host_build):
     # ccontrol's loop (descent = 2^-11 tanh(lag/100), hold 0.9 |lag/(p fs)|, sync_threshold) over
     # the modelled resampler: every row ends synchronized with zero residual delay, the engine then runs its
