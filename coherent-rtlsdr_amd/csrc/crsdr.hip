@@ -225,7 +225,7 @@ static hipError_t launch_xcorr_lag(hipStream_t s, const XcorrArgs &a, int row_co
 }
 
 // CRSDR_K1_VARIANT: "packed" (default) = xcorr14p.hpp, packed complex arithmetic; "scalar" = xcorr14.hpp, the same network
-// on scalar fp32 ops (bit-identical results); "half" = xcorr14h.hpp for K1 only, two rows per CU (experiment, scalar K0)
+// on scalar fp32 ops (bit-identical results).  (The measured-slower half-row-image experiment, dead end (8) of DESIGN.md, lives in tools/xcorr14h.hpp.)
 static char k1_variant()
 {
     // unset / "auto": the two-row kernel (q) for launches with enough rows per CU, the packed one (p) otherwise
@@ -267,7 +267,6 @@ static hipError_t launch_xcorr_lag14(hipStream_t s, const XcorrArgs &a, int row_
     if (variant == 'a') variant = items >= 12 * cus ? 'q' : 'p';
     if (variant == 'q' && !allow_q) variant = 'p';   // a plan whose two-row kernel once ran out of a bounded wait stays on the packed kernel
     if (used_q) *used_q = variant == 'q';
-    const bool half = variant == 'h';
     if (variant == 'p') {
         auto kp = x14p::k_xcorr_lag14p;
         hipError_t ep = hipFuncSetAttribute((const void *)kp, hipFuncAttributeMaxDynamicSharedMemorySize, x14::LDS_BYTES);
@@ -286,13 +285,6 @@ static hipError_t launch_xcorr_lag14(hipStream_t s, const XcorrArgs &a, int row_
         const hipError_t el = hipGetLastError();
         if (el == hipSuccess) *work_base += (unsigned)items;      // a launch that ran advances the device counter by exactly its item count (xcorr14q.hpp)
         return el;
-    }
-    if (half) {
-        auto kh = x14h::k_xcorr_lag14h;
-        hipError_t eh = hipFuncSetAttribute((const void *)kh, hipFuncAttributeMaxDynamicSharedMemorySize, x14h::LDS_BYTES_H);
-        if (eh != hipSuccess) return eh;
-        hipLaunchKernelGGL(kh, dim3(row_count, a.nblocks), dim3(x14h::THREADS_H), x14h::LDS_BYTES_H, s, a, twA, twB);
-        return hipGetLastError();
     }
     auto kern = x14::k_xcorr_lag14;
     hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, x14::LDS_BYTES);

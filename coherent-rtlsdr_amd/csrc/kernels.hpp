@@ -23,7 +23,6 @@
 #include "fft_lds.hpp"
 #include "plan_args.hpp"
 #include "xcorr14.hpp"
-#include "xcorr14h.hpp"
 #include "xcorr14p.hpp"
 #include "xcorr14q.hpp"
 #include "longblock.hpp"

@@ -536,7 +536,7 @@ def test_device_input_and_bound_packet_alignments(b, synth, B):
 
 
 def test_k1_variants_agree(tmp_path):
-    # CRSDR_K1_VARIANT: packed (xcorr14p.hpp; the default picks it or the two-row kernel q by launch size) must equal scalar (xcorr14.hpp) bit for bit; half selects xcorr14h.hpp (two rows per CU, even / odd plane trips through 66 KiB of LDS).
+    # CRSDR_K1_VARIANT: packed (xcorr14p.hpp; the default picks it or the two-row kernel q by launch size) must equal scalar (xcorr14.hpp) bit for bit.
     # The variant is chosen once per process, so it runs in a child: same lags, mag within 1e-5 (the last pass is
     # decimation-in-time instead of -in-frequency), same packets except +-1 LSB at rounding boundaries.
     import subprocess, sys, textwrap
@@ -568,7 +568,7 @@ def test_k1_variants_agree(tmp_path):
                  frac2=np.stack([o["frac"] for o in outs2]), d2=params2.d)
     ''') % root
     res = {}
-    for variant in ("scalar", "half", "packed", "q", "auto"):
+    for variant in ("scalar", "packed", "q", "auto"):
         out = tmp_path / f"{variant}.npz"
         env = dict(os.environ, CRSDR_K1_VARIANT=variant)
         r = subprocess.run([sys.executable, "-c", code, str(out)], env=env, capture_output=True, text=True, timeout=300)
@@ -583,12 +583,6 @@ def test_k1_variants_agree(tmp_path):
         assert np.array_equal(res["packed"][key].view(np.uint8), res["q"][key].view(np.uint8)), ("q", key)
         assert np.array_equal(res["packed"][key].view(np.uint8), res["auto"][key].view(np.uint8)), ("auto", key)
     assert np.array_equal(res["q"]["lag2"][0, 1:], res["q"]["d2"])
-    f, h = res["scalar"], res["half"]
-    assert np.array_equal(h["lag"], f["lag"]) and np.array_equal(h["lag"][0, 1:], f["d"])
-    assert np.allclose(h["mag"], f["mag"], rtol=1e-5)
-    assert np.allclose(h["frac"], f["frac"], atol=1e-3)
-    d = h["packet"].astype(np.int16) - f["packet"].astype(np.int16)
-    assert np.abs(d).max() <= 1 and np.count_nonzero(d) <= 1e-4 * d.size
 
 
 def test_two_row_kernel_reports_a_wait_that_ran_out(tmp_path):

@@ -1,3 +1,5 @@
+// (experiment, not part of libcrsdr.so any more: kept for the record of DESIGN.md dead end (8); it built against the csrc/ headers
+// of round 1 as K1 variant "half" and measured 15 % slower than the packed kernel)
 // xcorr14h.hpp -- K1 for B = 16384 with HALF the row in LDS: two workgroups (two rows) per CU.
 //
 // Why: with the whole 128 KiB row in LDS (xcorr14.hpp) one workgroup fills the CU, both waves of a SIMD belong to
