@@ -225,7 +225,8 @@ static hipError_t launch_xcorr_lag(hipStream_t s, const XcorrArgs &a, int row_co
 }
 
 // CRSDR_K1_VARIANT: "packed" (default) = xcorr14p.hpp, packed complex arithmetic; "scalar" = xcorr14.hpp, the same network
-// on scalar fp32 ops (bit-identical results).  (The measured-slower half-row-image experiment, dead end (8) of DESIGN.md, lives in tools/xcorr14h.hpp.)
+// on scalar fp32 ops (bit-identical results).  (Two measured-slower experiments live in tools/: xcorr14h.hpp, half-row LDS images -- dead end (8) of DESIGN.md -- and
+// xcorr14w.hpp, 1024 threads per row with the radix-32 transforms shared by lane pairs -- dead end (11).)
 static char k1_variant()
 {
     // unset / "auto": the two-row kernel (q) for launches with enough rows per CU, the packed one (p) otherwise
