@@ -40,6 +40,30 @@ __device__ __forceinline__ c2 cmulc(c2 a, c2 b)
 template <int DIR>
 __device__ __forceinline__ c2 ctw(c2 a, c2 w) { return DIR < 0 ? cmul(a, w) : cmulc(a, w); }
 
+// c + a * conj(b) as two fused multiply-adds:  (fma(a.y, b.y, fma(a.x, b.x, c.x)),  fma(-a.x, b.y, fma(a.y, b.x, c.y)))
+__device__ __forceinline__ c2 cmulc_add(c2 c, c2 a, c2 b)
+{
+    c2 r1, r;
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[1,0,1]" : "=v"(r1) : "v"(a), "v"(b), "v"(c));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_hi:[1,0,0]" : "=v"(r) : "v"(a), "v"(b), "v"(r1));
+    return r;
+}
+// c + a * b:  (fma(-a.y, b.y, fma(a.x, b.x, c.x)),  fma(a.x, b.y, fma(a.y, b.x, c.y)))
+__device__ __forceinline__ c2 cmul_add(c2 c, c2 a, c2 b)
+{
+    c2 r1, r;
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[1,0,1]" : "=v"(r1) : "v"(a), "v"(b), "v"(c));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0]" : "=v"(r) : "v"(a), "v"(b), "v"(r1));
+    return r;
+}
+// 2 p - s in one instruction: the difference of a radix-2 butterfly whose sum s = p + q is already there (q = s - p)
+__device__ __forceinline__ c2 twice_minus(c2 p, c2 s)
+{
+    c2 r;
+    asm("v_pk_fma_f32 %0, %1, 2.0, %2 op_sel_hi:[1,0,1] neg_lo:[0,0,1] neg_hi:[0,0,1]" : "=v"(r) : "v"(p), "v"(s));
+    return r;
+}
+
 // a + (-i) x = (a.x + x.y, a.y - x.x)      a - (-i) x = (a.x - x.y, a.y + x.x)
 __device__ __forceinline__ c2 add_mi(c2 a, c2 x)
 {
@@ -136,6 +160,46 @@ __device__ __forceinline__ void dft16(c2 *v)
     dft4<DIR>(v[4], v[5], v[6], v[7]);
     dft4<DIR>(v[8], v[9], v[10], v[11]);
     dft4<DIR>(v[12], v[13], v[14], v[15]);
+    c2 t;
+    t = v[1]; v[1] = v[4]; v[4] = t;
+    t = v[2]; v[2] = v[8]; v[8] = t;
+    t = v[3]; v[3] = v[12]; v[12] = t;
+    t = v[6]; v[6] = v[9]; v[9] = t;
+    t = v[7]; v[7] = v[13]; v[13] = t;
+    t = v[11]; v[11] = v[14]; v[14] = t;
+}
+
+// Junction of the cross-correlation: u[i] * r[i] (the conjugated reference spectrum) followed by the inverse 16-point DFT,
+// with the products folded into the first radix-4 stage:  t0 = a ra + c rc as p = a ra, t0 = p + c rc (two fused
+// multiply-adds), t1 = a ra - c rc = 2 p - t0 -- 10 packed instructions per radix-4 butterfly head instead of 12.
+__device__ __forceinline__ void dft4_inv_mul(c2 &a, c2 &b, c2 &c, c2 &d, c2 ra, c2 rb, c2 rc, c2 rd)
+{
+    const c2 pa = cmul(a, ra), t0 = cmul_add(pa, c, rc), t1 = twice_minus(pa, t0);
+    const c2 pb = cmul(b, rb), t2 = cmul_add(pb, d, rd), u = twice_minus(pb, t2);
+    a = t0 + t2;
+    c = t0 - t2;
+    b = add_j<+1>(t1, u);
+    d = sub_j<+1>(t1, u);
+}
+__device__ __forceinline__ void dft16_inv_mul(c2 *v, const c2 *r)
+{
+    dft4_inv_mul(v[0], v[4], v[8], v[12], r[0], r[4], r[8], r[12]);
+    dft4_inv_mul(v[1], v[5], v[9], v[13], r[1], r[5], r[9], r[13]);
+    dft4_inv_mul(v[2], v[6], v[10], v[14], r[2], r[6], r[10], r[14]);
+    dft4_inv_mul(v[3], v[7], v[11], v[15], r[3], r[7], r[11], r[15]);
+    v[5] = mul_w16<+1, 1>(v[5]);
+    v[9] = mul_w16<+1, 2>(v[9]);
+    v[13] = mul_w16<+1, 3>(v[13]);
+    v[6] = mul_w16<+1, 2>(v[6]);
+    v[10] = mul_w16<+1, 4>(v[10]);
+    v[14] = mul_w16<+1, 6>(v[14]);
+    v[7] = mul_w16<+1, 3>(v[7]);
+    v[11] = mul_w16<+1, 6>(v[11]);
+    v[15] = mul_w16<+1, 9>(v[15]);
+    dft4<+1>(v[0], v[1], v[2], v[3]);
+    dft4<+1>(v[4], v[5], v[6], v[7]);
+    dft4<+1>(v[8], v[9], v[10], v[11]);
+    dft4<+1>(v[12], v[13], v[14], v[15]);
     c2 t;
     t = v[1]; v[1] = v[4]; v[4] = t;
     t = v[2]; v[2] = v[8]; v[8] = t;

@@ -98,6 +98,38 @@ __device__ __forceinline__ void tw_apply(c2 *v, const c2 *w)
     }
 }
 
+// Inverse-pass head: the input twiddles (conjugated) folded into the first radix-2 stage of the 32-point transform.
+//   separate:  a' = a conj(wa), b' = b conj(wb)  [2 + 2],  s = a' + b', t = a' - b'  [1 + 1]          = 6 packed instructions
+//   fused:     p = a conj(wa) [2],  s = p + b conj(wb)  [2 fused multiply-adds],  t = 2 p - s  [1]        = 5
+// (index 0 carries no twiddle: 3 against 4).  16 fewer per pass; s rounds once less, t inherits s's rounding.
+#ifndef CRSDR_K1_FUSED_TW
+#define CRSDR_K1_FUSED_TW 1
+#endif
+template <int I>
+__device__ __forceinline__ void tw_stage1_inv(c2 *v, const c2 *w)
+{
+    if constexpr (I < 16) {
+        const c2 p = (I == 0) ? v[0] : cmulc(v[I], w[I]);
+        const c2 s = cmulc_add(p, v[I + 16], w[I + 16]);
+        const c2 t = twice_minus(p, s);
+        v[I] = s;
+        v[I + 16] = mul_w32<+1, I>(t);
+        tw_stage1_inv<I + 1>(v, w);
+    }
+}
+// v[k] = input k (natural order) -> inverse 32-point DFT of (v[k] conj(w[k])), outputs as dft32 leaves them (xpos)
+__device__ __forceinline__ void tw_dft32_inv(c2 *v, const c2 *w)
+{
+#if CRSDR_K1_FUSED_TW
+    tw_stage1_inv<0>(v, w);
+    dft16p<+1>(v);
+    dft16p<+1>(v + 16);
+#else
+    tw_apply<+1, false, 1>(v, w);
+    dft32<+1>(v);
+#endif
+}
+
 template <bool IS_REF>
 __device__ __forceinline__ void pass0_forward(c2 *A, const int8_t *__restrict__ row, const c2 *__restrict__ twA,
                                               uint32_t xor80, int tid, c2 *w)
@@ -143,8 +175,7 @@ __device__ __forceinline__ void pass1_inverse(c2 *A, const c2 *w, int tid)
     c2 v[32];
 #pragma unroll
     for (int k = 0; k < 32; ++k) v[k] = *(const volatile lds_c2 *)(Ab + p1_off(k) + (n2 ^ p1_swz(k)));   // ds_read_b64, not read2 (see pass1_forward)
-    tw_apply<+1, false, 1>(v, w);
-    dft32<+1>(v);
+    tw_dft32_inv(v, w);
 #pragma unroll
     for (int i = 0; i < 32; ++i) Ab[p1_off(i) + (n2 ^ p1_swz(i))] = v[xpos(i)];
 }
@@ -193,12 +224,21 @@ __device__ __forceinline__ void xcorr_row14(const XcorrArgs &a, unsigned char *s
             u[2 * j + 1] = mk(q.z, q.w);
         }
         dft16p<-1>(u);
+#if CRSDR_K1_FUSED_TW
+        {
+            c2 rr[16];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { rr[2 * j] = mk(r[j].x, r[j].y); rr[2 * j + 1] = mk(r[j].z, r[j].w); }
+            dft16_inv_mul(u, rr);
+        }
+#else
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             u[2 * j] = cmul(u[2 * j], mk(r[j].x, r[j].y));
             u[2 * j + 1] = cmul(u[2 * j + 1], mk(r[j].z, r[j].w));
         }
         dft16p<+1>(u);
+#endif
 #pragma unroll
         for (int j = 0; j < 8; ++j)
             A4[base + (j ^ key)] = make_float4(u[2 * j].x, u[2 * j].y, u[2 * j + 1].x, u[2 * j + 1].y);
@@ -216,8 +256,7 @@ __device__ __forceinline__ void xcorr_row14(const XcorrArgs &a, unsigned char *s
         const int base = p0_base(tid);
 #pragma unroll
         for (int k = 0; k < 32; ++k) v[k] = A[base + k * 528];
-        tw_apply<+1, false, 1>(v, wA);
-        dft32<+1>(v);
+        tw_dft32_inv(v, wA);
 #pragma unroll
         for (int i = 0; i < 32; ++i) {
             const c2 x = v[xpos(i)];
@@ -463,12 +502,21 @@ __global__ __launch_bounds__(THREADS, 2) void k_rows14_cf32p(c2 *__restrict__ Y,
             for (int j = 0; j < 8; ++j)
                 refspec4[j * 1024 + g] = make_float4(u[2 * j].x, -u[2 * j].y, u[2 * j + 1].x, -u[2 * j + 1].y);
         } else {
+#if CRSDR_K1_FUSED_TW
+            {
+                c2 rr[16];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { rr[2 * j] = mk(r[j].x, r[j].y); rr[2 * j + 1] = mk(r[j].z, r[j].w); }
+                dft16_inv_mul(u, rr);
+            }
+#else
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 u[2 * j] = cmul(u[2 * j], mk(r[j].x, r[j].y));
                 u[2 * j + 1] = cmul(u[2 * j + 1], mk(r[j].z, r[j].w));
             }
             dft16p<+1>(u);
+#endif
 #pragma unroll
             for (int j = 0; j < 8; ++j)
                 A4[base + (j ^ key)] = make_float4(u[2 * j].x, u[2 * j].y, u[2 * j + 1].x, u[2 * j + 1].y);
@@ -484,8 +532,7 @@ __global__ __launch_bounds__(THREADS, 2) void k_rows14_cf32p(c2 *__restrict__ Y,
         for (int k = 0; k < 32; ++k) v[k] = A[base + k * 528];
         c2 w[32];
         tw_load(w, twA, TWA_STRIDE, tid);
-        tw_apply<+1, false, 1>(v, w);
-        dft32<+1>(v);
+        tw_dft32_inv(v, w);
 #pragma unroll
         for (int i = 0; i < 32; ++i) line[i * 512 + tid] = v[xpos(i)]; // natural order, coalesced
     }

@@ -133,8 +133,7 @@ __device__ __forceinline__ void q_p0i_compute(float *m, c2 *v, const c2 *__restr
 {
     c2 w[32];
     tw_load(w, twA, TWA_STRIDE, vt);
-    tw_apply<+1, false, 1>(v, w);
-    dft32<+1>(v);
+    tw_dft32_inv(v, w);
 #pragma unroll
     for (int i = 0; i < 32; ++i) {
         const c2 x = v[xpos(i)];
@@ -161,12 +160,21 @@ __device__ __forceinline__ void q_junction_half(float4 *A4, const float4 *r, int
         u[2 * j + 1] = mk(q.z, q.w);
     }
     dft16p<-1>(u);
+#if CRSDR_K1_FUSED_TW
+    {
+        c2 rr[16];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { rr[2 * j] = mk(r[j].x, r[j].y); rr[2 * j + 1] = mk(r[j].z, r[j].w); }
+        dft16_inv_mul(u, rr);
+    }
+#else
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         u[2 * j] = cmul(u[2 * j], mk(r[j].x, r[j].y));
         u[2 * j + 1] = cmul(u[2 * j + 1], mk(r[j].z, r[j].w));
     }
     dft16p<+1>(u);
+#endif
 #pragma unroll
     for (int j = 0; j < 8; ++j)
         A4[base + (j ^ key)] = make_float4(u[2 * j].x, u[2 * j].y, u[2 * j + 1].x, u[2 * j + 1].y);

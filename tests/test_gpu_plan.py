@@ -536,7 +536,7 @@ def test_device_input_and_bound_packet_alignments(b, synth, B):
 
 
 def test_k1_variants_agree(tmp_path):
-    # CRSDR_K1_VARIANT: packed (xcorr14p.hpp; the default picks it or the two-row kernel q by launch size) must equal scalar (xcorr14.hpp) bit for bit.
+    # CRSDR_K1_VARIANT: packed (xcorr14p.hpp; the default picks it or the two-row kernel q by launch size) must agree with scalar (xcorr14.hpp) to rounding, and with each other bit for bit.
     # The variant is chosen once per process, so it runs in a child: same lags, mag within 1e-5 (the last pass is
     # decimation-in-time instead of -in-frequency), same packets except +-1 LSB at rounding boundaries.
     import subprocess, sys, textwrap
@@ -574,11 +574,18 @@ def test_k1_variants_agree(tmp_path):
         r = subprocess.run([sys.executable, "-c", code, str(out)], env=env, capture_output=True, text=True, timeout=300)
         assert r.returncode == 0, r.stdout + r.stderr
         res[variant] = np.load(out)
-    # the packed kernel (default) rounds every operation like the scalar one: identical bits
     for key in ("lag", "mag", "frac", "packet"):
-        assert np.array_equal(res["packed"][key].view(np.uint8), res["scalar"][key].view(np.uint8)), key
-        # q: the packed passes run by one persistent workgroup per CU, two rows in opposite phases (xcorr14q.hpp)
+        # q: the packed passes run by one persistent workgroup per CU, two rows in opposite phases (xcorr14q.hpp): identical bits
         assert np.array_equal(res["packed"][key].view(np.uint8), res["q"][key].view(np.uint8)), ("q", key)
+    # scalar (xcorr14.hpp): the same network on scalar fp32 ops.  The packed kernels fold the inverse passes' input twiddles
+    # and the junction's products into fused multiply-adds (r02), so the two agree to rounding, not to the bit: same lags,
+    # mag to 1e-5, packets equal except +-1 LSB at rounding boundaries
+    f, sc = res["packed"], res["scalar"]
+    assert np.array_equal(sc["lag"], f["lag"]) and np.array_equal(sc["lag2"], f["lag2"])
+    assert np.allclose(sc["mag"], f["mag"], rtol=1e-5) and np.allclose(sc["mag2"], f["mag2"], rtol=1e-5)
+    assert np.allclose(sc["frac"], f["frac"], atol=1e-3) and np.allclose(sc["frac2"], f["frac2"], atol=1e-3)
+    d = sc["packet"].astype(np.int16) - f["packet"].astype(np.int16)
+    assert np.abs(d).max() <= 1 and np.count_nonzero(d) <= 1e-4 * d.size
     for key in ("lag2", "mag2", "frac2"):      # 3200 items (>= 12 per CU): "auto" takes the two-row kernel here as well
         assert np.array_equal(res["packed"][key].view(np.uint8), res["q"][key].view(np.uint8)), ("q", key)
         assert np.array_equal(res["packed"][key].view(np.uint8), res["auto"][key].view(np.uint8)), ("auto", key)
