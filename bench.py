@@ -48,6 +48,8 @@ def parse():
     ap.add_argument("--frac-apply", action="store_true", help="with --cfg5: fractional-delay correction on (crsdr_plan_set_frac_apply, D = this block's estimate)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the locked-mode / large-working-set extras")
+    ap.add_argument("--skip-pcie", action="store_true", help="skip the host-buffer (PCIe-inclusive) extra: its submits carry 16 blocks, "
+                    "which would mix launch sizes into a profile whose per-kernel averages are meant for 64-block launches")
     ap.add_argument("--cpu-blocks", type=int, default=0, help="oracle blocks to time (0 = auto, ~10-20 s)")
     ap.add_argument("--repeats", type=int, default=0, help="repeats of the timed region of exactly --steps steps, the median is reported "
                     "(0 = auto: 5 when the region is shorter than ~50 ms, else 1)")
@@ -322,6 +324,18 @@ def main():
             "env": _env(torch, dev, b, local_rank),
         }
 
+    if rank == 0 and args.cfg5:
+        # long blocks: "k_xcorr_lag" above is the whole four-step pipeline (stages A + B + C + finalize, events around all of it).
+        # Beside the algorithmic figure (each int8 input byte once), the traffic MODEL of DESIGN.md section 4: per signal row
+        # A reads B bytes and writes 8B, B reads and writes 8B, C reads 8B = 33 B bytes (66 MiB per 2 MiB row); the reference row
+        # adds 17 B bytes.  model_GBs says how fast the stages stream what the four-step algorithm has to move.
+        model = (33 * nsig + 17) * B
+        result["roofline"].update({"kernel": "long-block stages A+B+C (k_long_fwd_cols, k_rows14_cf32p, k_long_inv_cols)",
+                                   "traffic_model_bytes_per_block": model, "traffic_model_GBs": model / (k1 * 1e-3) / 1e9,
+                                   "traffic_model_frac": model / (k1 * 1e-3) / 1e9 / HBM_PEAK_GBS, "frac_apply": bool(args.frac_apply),
+                                   "note": "HBM-streaming regime: the four-step transform moves 33x the algorithmic bytes through HBM / the memory-side cache "
+                                           "(cf32 intermediates); traffic_model_* prices the stages against that, achieved/frac against the int8 input alone"})
+
     # ---- extras: locked steady state (phase path only) ---------------------------------------------
     if not args.no_extras:
         fl_locked = flags | b.NO_LAG
@@ -362,7 +376,7 @@ def main():
                                 "note": "Rxx = X^H X / L of the 1024 signal rows, 3 int8 MFMA products, host-synchronous call"}
 
     # ---- extra: host-buffer (PCIe-inclusive) rate -- reported for DESIGN.md, never `value` -----------
-    if not args.no_extras and world == 1:
+    if not args.no_extras and not args.skip_pcie and world == 1:
         Tp = min(T, 16)
         hp = b.Plan(nrows, B, mode, device=local_rank, max_batch=Tp)
         hstride = hp.packet_stride

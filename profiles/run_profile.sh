@@ -7,7 +7,7 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-ARGS="--steps 128 --warmup 64 --no-cpu-baseline $@"   # every launch carries the default 64 blocks
+ARGS="--steps 128 --warmup 64 --no-cpu-baseline --skip-pcie $@"   # every launch carries the default 64 blocks (the PCIe extra submits 16 at a time: skipped)
 # pass 1: kernel trace + stats (no counters)
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $ROOT/bench.py $ARGS > $OUT/trace.log 2>&1 || echo "trace pass failed"
 # separate PMC passes (never combined with sys/hip/hsa traces)
