@@ -333,6 +333,8 @@ def main():
         result["roofline"].update({"kernel": "long-block stages A+B+C (k_long_fwd_cols, k_rows14_cf32p, k_long_inv_cols)",
                                    "traffic_model_bytes_per_block": model, "traffic_model_GBs": model / (k1 * 1e-3) / 1e9,
                                    "traffic_model_frac": model / (k1 * 1e-3) / 1e9 / HBM_PEAK_GBS, "frac_apply": bool(args.frac_apply),
+                                   "traffic": None, "traffic_source": "per-stage PMC bytes of this configuration: profiles/r02_cfg5_traffic_notes.json "
+                                                                      "(stage writes equal the model exactly; not rescaled into this line)",
                                    "note": "HBM-streaming regime: the four-step transform moves 33x the algorithmic bytes through HBM / the memory-side cache "
                                            "(cf32 intermediates); traffic_model_* prices the stages against that, achieved/frac against the int8 input alone"})
 

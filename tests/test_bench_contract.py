@@ -16,9 +16,17 @@ CPU_KEYS = {"value", "unit", "cores", "kind", "sample"}
 
 
 def _latest_record():
+    # from round 2 on: one default-arguments record per round, profiles/rNN_bench_default.json (round 1 kept a numbered history)
+    recs = sorted(glob.glob(os.path.join(PROFILES, "r*_bench_default.json")))
+    if recs:
+        return recs[-1]
     recs = glob.glob(os.path.join(PROFILES, "r*_bench_v*.json"))
     assert recs, "no committed bench record under profiles/"
     return max(recs, key=lambda p: int(re.search(r"_v(\d+)", os.path.basename(p)).group(1)))
+
+
+def _latest_round():
+    return os.path.basename(_latest_record())[:3]
 
 
 def test_latest_bench_record_keeps_the_contract():
@@ -42,16 +50,22 @@ def test_latest_bench_record_keeps_the_contract():
     c = d["cpu_baseline"]
     assert CPU_KEYS <= set(c) and c["kind"] in ("reference", "port") and c["cores"] >= 1 and c["value"] > 0
     assert d["lags_exact"] is True
+    if "repeats" in d:                                  # r02: the timed region is repeated, value is the median
+        lo, hi = d["value_spread"]
+        assert d["repeats"] >= 1 and lo <= d["value"] <= hi
+        assert d["batches_timed"]["whole"] * d["batches_timed"]["blocks_per_batch"] + d["batches_timed"]["ragged_blocks"] == d["steps"]
+        assert r["traffic"] is None or "profiles/" in r["traffic_source"]      # the traffic figure names the committed pass it comes from
 
 
 def test_committed_traffic_matches_the_pmc_summary():
-    t = json.load(open(os.path.join(PROFILES, "r01_traffic.json")))
+    rnd = _latest_round()
+    t = json.load(open(os.path.join(PROFILES, f"{rnd}_traffic.json")))
     for key in ("k_xcorr_lag", "k_align_fused"):
         e = t[key]
         # FETCH_SIZE / WRITE_SIZE are KiB; the read side is doubled as MI355X_MICROARCH.md prescribes for gfx950
         assert abs(e["bytes_per_launch"] - (2 * e["fetch_size_raw_kib"] + e["write_size_raw_kib"]) * 1024) < 1024     # raw values are rounded to 0.1 KiB
         assert 0.9 < e["bytes_per_launch"] / e["algorithmic_bytes_per_launch"] < 1.25, key     # no wasted re-reads
-    summary = open(os.path.join(PROFILES, "r01", "rocprofv3_summary_final.txt")).read()
+    summary = open(os.path.join(PROFILES, rnd, "rocprofv3_summary_final.txt" if rnd == "r01" else "rocprofv3_summary.txt")).read()
     for kernel in ("k_xcorr_lag14", "k_align_fused"):
         assert kernel in summary
     # the kernel-trace average for K1 and the bench record's HIP-event average describe the same launches
