@@ -331,6 +331,26 @@ static hipError_t launch_long_fwd_cols(hipStream_t s, int nrows_launch, const in
     hipLaunchKernelGGL(kern, dim3(lb::ntiles(LOG2N1), nrows_launch), dim3(lb::THREADS), lb::LDS_BYTES, s, rows, row_begin, xor80, tw, Y);
     return hipGetLastError();
 }
+// stage B with two lines per CU in opposite phases (k_rows14_cf32q): a line's HBM phases run beside the other line's transforms
+static hipError_t launch_long_rows_q(hipStream_t s, int n1, int nrows_launch, float2 *Y, const float2 *twA, const float2 *twB, float2 *refspec,
+                                     int *waitflag, unsigned int *work, unsigned int *work_base)
+{
+    static const int cus = [] {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 1) n = 256;
+        return n;
+    }();
+    auto kq = x14p::k_rows14_cf32q;
+    hipError_t e = hipFuncSetAttribute((const void *)kq, hipFuncAttributeMaxDynamicSharedMemorySize, x14p::LDSQ_BYTES);
+    if (e != hipSuccess) return e;
+    const int items = n1 * nrows_launch;
+    static const int qspin = [] { const char *ev = getenv("CRSDR_K1_QSPIN"); return ev ? atoi(ev) : x14p::kQSpinLimit; }();
+    hipLaunchKernelGGL(kq, dim3((unsigned)std::max(1, std::min(cus, (items + 1) / 2))), dim3(2 * x14p::QG), x14p::LDSQ_BYTES, s, reinterpret_cast<c2 *>(Y),
+                       reinterpret_cast<const c2 *>(twA), reinterpret_cast<const c2 *>(twB), (const float4 *)refspec, n1, items, waitflag, work, *work_base, qspin);
+    e = hipGetLastError();
+    if (e == hipSuccess) *work_base += (unsigned)items;
+    return e;
+}
 // stage B: the 16384-point row transforms run on the 32x32x16 structure of xcorr14.hpp
 template <bool IS_REF>
 static hipError_t launch_long_rows(hipStream_t s, int n1, int nrows_launch, float2 *Y, const float2 *twA, const float2 *twB, float2 *refspec)
@@ -1180,7 +1200,19 @@ extern "C" int crsdr_plan_submit_batch(crsdr_plan *p, const void *rows, int mem_
             const int cnt = std::min(p->long_chunk, p->row_count - r0);
             float2 *Yc = p->d_Y + (size_t)r0 * (size_t)p->B;
             HIP_TRY(CRSDR_DISPATCH_N1(l1, (launch_long_fwd_cols<LG, false>(S, cnt, d_in, p->row_begin + r0, xor80, tw, Yc))));
-            HIP_TRY(launch_long_rows<false>(S, n1, cnt, Yc, p->d_twA, p->d_twB, p->d_refspec[0]));
+            // stage B: two lines per CU (k_rows14_cf32q) once a launch has enough lines per CU; the packed one-line kernel otherwise
+            // (and always under CRSDR_K1_VARIANT=packed|scalar, or after a bounded wait of the two-line kernels ran out)
+            static const int longq = [] { const char *e = getenv("CRSDR_LONG_Q"); return e ? atoi(e) : 1; }();
+            const char kv = k1_variant();
+            if (longq && (kv == 'a' || kv == 'q') && !p->q_disabled && (long)n1 * cnt >= 1024) {
+                if (!p->snap_valid) {                      // same rollback protocol as the two-row K1 (check_fused_status)
+                    p->snap_valid = true; p->snap_phase_cur = p->phase_cur;
+                    HIP_TRY(hipMemcpyAsync(p->d_state_snap, p->d_state, p->state_bytes, hipMemcpyDeviceToDevice, S));
+                }
+                HIP_TRY(launch_long_rows_q(S, n1, cnt, Yc, p->d_twA, p->d_twB, p->d_refspec[0], reinterpret_cast<int *>(p->d_sync + 2), p->d_sync + 3, &p->q_work_base));
+                p->k1_used = true;
+            } else
+                HIP_TRY(launch_long_rows<false>(S, n1, cnt, Yc, p->d_twA, p->d_twB, p->d_refspec[0]));
             HIP_TRY(CRSDR_DISPATCH_N1(l1, (launch_long_inv_cols<LG>(S, cnt, Yc, tw, p->d_part + (size_t)r0 * lb::ntiles(l1)))));
         }
         hipLaunchKernelGGL(lb::k_long_finalize, dim3(p->row_count), dim3(256), 0, S, p->d_Y, p->d_part, tw, n1, lb::ntiles(l1), xa);
@@ -1188,7 +1220,9 @@ extern "C" int crsdr_plan_submit_batch(crsdr_plan *p, const void *rows, int mem_
         if (pe1) HIP_TRY(hipEventRecord(pe1[1], S));
     } else if (any_lag) {
         const int slot = (p->slot ^= 1);
-        // K0 on the aux stream: with resident input it overlaps the previous batch's K1 / K2
+        // K0 on the aux stream: with resident input it overlaps the previous batch's K1 / K2.  (Putting it on the main stream
+        // when both streams are idle -- a cold batch -- was measured in r02: exposed K0 0.0526 -> 0.0516 ms per cold batch and
+        // no difference beyond the spread in a 20-block timed region; not kept.)
         const bool forked = !input_ready || d_readcnt || d_mask;
         if (forked) {
             HIP_TRY(hipEventRecord(p->ev_fork, S)); // input copies, mask copy / the caller's producer work

@@ -223,7 +223,8 @@ __global__ __launch_bounds__(2 * QG, 1) void k_xcorr_lag14q(XcorrArgs a, const f
         int vt0 = tid, vt1 = tid + QG;
         asm volatile("" : "+v"(vt0), "+v"(vt1));
         if ((unsigned)item >= (unsigned)nitems) break;     // also ends on a negative item (host / device counters out of step)
-        const int t = item / row_count, row = a.row_begin + item % row_count;
+        const int item_u = __builtin_amdgcn_readfirstlane(item);           // one item per group: scalar row / block addresses
+        const int t = item_u / row_count, row = a.row_begin + item_u % row_count;
         if (xcorr_skip(a, row, t, tid)) {
             q_barrier(sy, g, gen, 5);           // every wave of the group has read this item from next[g] before it is overwritten
             if (tid == 0) sy->next[g] = 2 * (int)gridDim.x + (int)(atomicAdd(work, 1u) - work_base);
@@ -343,6 +344,104 @@ __global__ __launch_bounds__(2 * QG, 1) void k_xcorr_lag14q(XcorrArgs a, const f
     if (threadIdx.x == 0 && errflag) {
         // both groups may still be running: the flag is only ever set, so reading it here can miss a late error of the
         // other group -- thread 256 reports as well
+        if (__hip_atomic_load(&sy->err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) atomicAdd(errflag, 1);
+    }
+    if (threadIdx.x == QG && errflag) {
+        if (__hip_atomic_load(&sy->err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) atomicAdd(errflag, 1);
+    }
+}
+
+// ---- stage B of the long-block path (longblock.hpp) on the same two-lines-per-CU structure -----------------------------
+// k_rows14_cf32p<false> costs a CU its line's load phase + ~10 us of transforms + its store phase one after the other (one
+// 132 KiB image per CU, so no second workgroup hides them): 18.6 us per 128 KiB line.  Here a line's loads, first radix-32
+// pass, last pass and stores are the OUTER section of a group and run beside the other group's image-owning middle section,
+// exactly as the int8 loads and the epilogue do in k_xcorr_lag14q.  cf32 in and out, in place; forward, x conj(ref), inverse.
+// items = lines: item i is line i of Y (row i / n1, frequency k1 = i % n1 -> its slice of the reference spectrum).
+__device__ __forceinline__ void q_line_p0_compute(c2 *v, const c2 *__restrict__ line, const c2 *__restrict__ twA, int vt)
+{
+#pragma unroll
+    for (int i = 0; i < 32; ++i) v[i] = line[i * 512 + vt];
+    dft32<-1>(v);
+    c2 w[32];
+    tw_load(w, twA, TWA_STRIDE, vt);
+    tw_apply<-1, true, 1>(v, w);
+}
+__device__ __forceinline__ void q_line_p0i_store(c2 *__restrict__ line, c2 *v, const c2 *__restrict__ twA, int vt)
+{
+    c2 w[32];
+    tw_load(w, twA, TWA_STRIDE, vt);
+    tw_dft32_inv(v, w);
+#pragma unroll
+    for (int i = 0; i < 32; ++i) line[i * 512 + vt] = v[xpos(i)];      // natural order, coalesced
+}
+
+__global__ __launch_bounds__(2 * QG, 1) void k_rows14_cf32q(c2 *__restrict__ Y, const c2 *__restrict__ twA, const c2 *__restrict__ twB,
+                                                           const float4 *__restrict__ refspec_base, int n1, int nitems, int *__restrict__ errflag,
+                                                           unsigned int *__restrict__ work, unsigned int work_base, int spin_limit)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    c2 *A = reinterpret_cast<c2 *>(smem);
+    float4 *A4 = reinterpret_cast<float4 *>(smem);
+    const int g = threadIdx.x >> 8, tid = threadIdx.x & (QG - 1);
+    QSync *sy = reinterpret_cast<QSync *>(smem + (size_t)LDS_ELEMS * 8 + 1024);
+    if (threadIdx.x == 0) { sy->owner = 0; sy->relcnt = 0; sy->bar[0] = 0; sy->bar[1] = 0; sy->err = 0; sy->next[0] = 0; sy->next[1] = 0; sy->spin_limit = spin_limit; }
+    __syncthreads();
+    int gen = 0;
+    int item = g * (int)gridDim.x + (int)blockIdx.x;     // then from the global counter, as in k_xcorr_lag14q
+    for (int k = 0;; ++k) {
+        int vt0 = tid, vt1 = tid + QG;
+        asm volatile("" : "+v"(vt0), "+v"(vt1));
+        if ((unsigned)item >= (unsigned)nitems) break;
+        const int item_u = __builtin_amdgcn_readfirstlane(item);          // one item per group: scalar base addresses
+        c2 *line = Y + (size_t)item_u * N;
+        const float4 *__restrict__ refspec4 = refspec_base + (size_t)(item_u % n1) * (N / 2);
+        c2 wB[32];
+        {
+            c2 v[32], v2[32];
+            q_line_p0_compute(v, line, twA, vt0);
+            __builtin_amdgcn_sched_barrier(0);           // keep the second half's 64 load registers out of the first half's transform
+            q_line_p0_compute(v2, line, twA, vt1);
+            __builtin_amdgcn_sched_barrier(0);
+            tw_load(wB, twB, TWB_STRIDE, tid & 15);
+            q_acquire(sy, 2 * k + g + 1);
+            __builtin_amdgcn_s_setprio(Q_PRIO);
+            q_p0_store(A, v, vt0);
+            q_p0_store(A, v2, vt1);
+        }
+        float4 ra[8], rb[8];
+        q_refspec_load(ra, refspec4, vt0, 0);
+        q_barrier(sy, g, gen, 0);
+        pass1_forward(A, wB, vt0);
+        pass1_forward(A, wB, vt1);
+        wave_lds_sync();
+        q_refspec_load(rb, refspec4, vt0, 1);
+        q_junction_half(A4, ra, vt0, 0);
+        q_refspec_load(ra, refspec4, vt1, 0);
+        q_junction_half(A4, rb, vt0, 1);
+        q_refspec_load(rb, refspec4, vt1, 1);
+        q_junction_half(A4, ra, vt1, 0);
+        q_junction_half(A4, rb, vt1, 1);
+        wave_lds_sync();
+        pass1_inverse(A, wB, vt0);
+        pass1_inverse(A, wB, vt1);
+        q_barrier(sy, g, gen, 1);
+        if (tid == 0) sy->next[g] = 2 * (int)gridDim.x + (int)(atomicAdd(work, 1u) - work_base);
+        {
+            c2 v[32], v2[32];
+            q_p0i_load(v, A, vt0);
+            q_p0i_load(v2, A, vt1);
+            q_release(sy);                               // the line is in registers: the image goes to the other group
+            __builtin_amdgcn_s_setprio(0);
+            int vs0 = tid, vs1 = tid + QG;               // opaque again: 64 load addresses kept for the stores would be 128 registers
+            asm volatile("" : "+v"(vs0), "+v"(vs1));
+            q_line_p0i_store(line, v, twA, vs0);
+            __builtin_amdgcn_sched_barrier(0);
+            q_line_p0i_store(line, v2, twA, vs1);
+        }
+        q_barrier(sy, g, gen, 2);                        // next[g] (written after barrier 1) is visible to the whole group
+        item = sy->next[g];
+    }
+    if (threadIdx.x == 0 && errflag) {
         if (__hip_atomic_load(&sy->err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) atomicAdd(errflag, 1);
     }
     if (threadIdx.x == QG && errflag) {

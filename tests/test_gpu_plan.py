@@ -592,6 +592,42 @@ def test_k1_variants_agree(tmp_path):
     assert np.array_equal(res["q"]["lag2"][0, 1:], res["q"]["d2"])
 
 
+def test_long_block_two_line_stage_b_is_bit_identical(tmp_path):
+    # stage B of the long-block path (the 16384-point line transforms x conj(ref)) runs two lines per CU in opposite phases
+    # (k_rows14_cf32q) once a launch has >= 1024 lines, the one-line packed kernel otherwise: the same passes on the same
+    # data, so lags, magnitudes and packets are equal bit for bit.  CRSDR_LONG_Q is read once per process -> children.
+    import subprocess, sys, textwrap
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = textwrap.dedent('''
+        import importlib, sys, numpy as np
+        sys.path.insert(0, %r)
+        pkg = importlib.import_module("coherent-rtlsdr_amd")
+        b, synth = pkg.binding, pkg.synth
+        res = {}
+        for name, nsig, log2B, nblk in (("many", 300, 16, 2), ("odd", 343, 15, 2), ("cfg5", 21, 21, 2)):
+            L = (1 << log2B) // 2
+            params = synth.RowParams(nsig, L, 31 + log2B)
+            plan = b.Plan(nsig + 1, 2 * L, b.MODE_DIGITAL)
+            for t in range(nblk):
+                rows, _ = synth.make_block(nsig, L, 31 + log2B, t, params=params)
+                out = plan.block(rows, seq=t)
+                assert np.array_equal(out["lag"][1:], params.d), name
+            for key in ("lag", "mag", "frac", "packet"):
+                res[name + "_" + key] = out[key]
+            plan.close()
+        np.savez(sys.argv[1], **res)
+    ''') % root
+    res = {}
+    for q in ("0", "1"):
+        out = tmp_path / f"longq{q}.npz"
+        r = subprocess.run([sys.executable, "-c", code, str(out)], env=dict(os.environ, CRSDR_LONG_Q=q), capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout + r.stderr
+        res[q] = np.load(out)
+    assert set(res["0"].files) == set(res["1"].files) and len(res["0"].files) == 12
+    for key in res["0"].files:
+        assert np.array_equal(res["0"][key].view(np.uint8), res["1"][key].view(np.uint8)), key
+
+
 def test_two_row_kernel_reports_a_wait_that_ran_out(tmp_path):
     # the two-row K1 (xcorr14q.hpp) bounds every wait for the LDS image / its group barriers.  With the bound forced to
     # zero polls (CRSDR_K1_QSPIN=0) waits do run out: the launch must terminate, the next sync / fetch must return an
