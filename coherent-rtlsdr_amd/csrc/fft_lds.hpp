@@ -170,6 +170,18 @@ __device__ __forceinline__ int digit_reverse(int j)
     return out;
 }
 
+template <int LOG2N>
+constexpr int digit_reverse_c(int j)                     // the same permutation for compile-time arguments
+{
+    using G = FftGeom<LOG2N>;
+    int out = 0, shift = 0;
+    for (int p = 0; p < G::NPASS; ++p) {
+        out |= ((j >> G::log2m(p)) & ((1 << G::log2r(p)) - 1)) << shift;
+        shift += G::log2r(p);
+    }
+    return out;
+}
+
 // One DIF pass (butterfly, then twiddle) or DIT pass (twiddle, then butterfly) over the whole
 // row in LDS.  tw = forward table W_N^k, k in [0,N).  Groups of R points with stride M; each
 // thread owns whole groups, so the pass is in place and needs a barrier only before / after.

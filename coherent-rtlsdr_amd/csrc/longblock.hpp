@@ -80,11 +80,37 @@ __device__ __forceinline__ void col_fft(float2 *T, const float2 *__restrict__ tw
     }
 }
 
+// ---- twiddles of the column passes ---------------------------------------------------------------------
+// A thread owns the same column pair (n2, n2 + 1) in 8 tile rows j(i) = j0 + S i, so its 16 twiddles are
+// W_B^(n2 k1(i)) with k1(i) = k0 + sum_b bit_b(i) ks[b]: four two-level table products and three levels of
+// products (<= 4 roundings, ~3e-7) per column instead of 8 x 2 gathered table entries -- a quarter of the
+// gathers.  (N1 >= 8; the two shortest block sizes keep the per-element table look-ups: their tiles are wider
+// than a thread's stride.)
+constexpr uint32_t FMASK = (1u << FBITS) - 1;
+struct Ladder {
+    float2 g[8];
+};
+__device__ __forceinline__ void ladder_issue(Ladder &l, const LongTw &t, uint32_t n2, uint32_t k0, uint32_t ks0, uint32_t ks1, uint32_t ks2)
+{
+    const uint32_t m[4] = {(n2 * k0) & t.bmask, (n2 * ks0) & t.bmask, (n2 * ks1) & t.bmask, (n2 * ks2) & t.bmask};
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        l.g[2 * q] = t.wc[m[q] >> FBITS];
+        l.g[2 * q + 1] = t.wf[m[q] & FMASK];
+    }
+}
+__device__ __forceinline__ void ladder_expand(const Ladder &l, float2 *w)
+{
+    const float2 b = cmul(l.g[0], l.g[1]), s0 = cmul(l.g[2], l.g[3]), s1 = cmul(l.g[4], l.g[5]), s2 = cmul(l.g[6], l.g[7]);
+    w[0] = b; w[1] = cmul(b, s0); w[2] = cmul(b, s1); w[3] = cmul(w[1], s1);
+    w[4] = cmul(b, s2); w[5] = cmul(w[1], s2); w[6] = cmul(w[2], s2); w[7] = cmul(w[3], s2);
+}
+
 // ---- A: int8 -> column FFTs -> x W_B^(n2 k1) -> Y[k1][n2] -------------------------------------------
 // grid (ntiles, rows); tile = columns [tile*C, (tile+1)*C), C = TILE / N1.  Signal rows carry samples at n < L
 // (n1 < N1/2), the ref row at n >= L (src/crtlsdr.cc:205-207,215-218).
 template <int LOG2N1, bool IS_REF>
-__global__ __launch_bounds__(THREADS, 2) void k_long_fwd_cols(const int8_t *__restrict__ rows, int row_begin, uint32_t xor80,
+__global__ __launch_bounds__(THREADS, 4) void k_long_fwd_cols(const int8_t *__restrict__ rows, int row_begin, uint32_t xor80,
                                                            LongTw tw, float2 *__restrict__ Y)
 {
     constexpr int N1 = 1 << LOG2N1, LOG2C = LOG2TILE - LOG2N1, C = 1 << LOG2C, H = N1 / 2;
@@ -102,6 +128,18 @@ __global__ __launch_bounds__(THREADS, 2) void k_long_fwd_cols(const int8_t *__re
         const int w = tid + i * THREADS, n1 = (2 * w) >> LOG2C, c = (2 * w) & (C - 1);
         u[i] = src[((size_t)n1 * N2 + (size_t)tile * C + c) >> 1];
     }
+    // the output twiddles' table entries: issued with the input loads, used after the column transforms
+    constexpr bool LADDER = LOG2N1 >= 3;
+    Ladder la, lb_;
+    if constexpr (LADDER) {
+        constexpr int LOG2S = LOG2N1 - 3;                        // a thread's tile rows: j0 + (i << LOG2S)
+        const uint32_t j0 = (uint32_t)(2 * tid) >> LOG2C, n2 = (uint32_t)(tile * C + ((2 * tid) & (C - 1)));
+        const uint32_t k0 = (uint32_t)rev_n1<LOG2N1>((int)j0);
+        constexpr uint32_t ks0 = (uint32_t)digit_reverse_c<LOG2N1>(1 << LOG2S), ks1 = (uint32_t)digit_reverse_c<LOG2N1>(2 << LOG2S),
+                           ks2 = (uint32_t)digit_reverse_c<LOG2N1>(4 << LOG2S);
+        ladder_issue(la, tw, n2, k0, ks0, ks1, ks2);
+        ladder_issue(lb_, tw, n2 + 1u, k0, ks0, ks1, ks2);
+    }
 #pragma unroll
     for (int i = 0; i < WORDS; ++i) {
         const int w = tid + i * THREADS, n1 = (2 * w) >> LOG2C, c = (2 * w) & (C - 1);
@@ -114,25 +152,36 @@ __global__ __launch_bounds__(THREADS, 2) void k_long_fwd_cols(const int8_t *__re
     __syncthreads();
     col_fft<LOG2N1, -1>(T, tw.tw1, tid);
     float2 *Yr = Y + (size_t)(IS_REF ? 0 : blockIdx.y) * B;
-    // a thread's 16 outputs as 8 column pairs: all 32 twiddle-table loads are issued before the first product
-    // (a rolled loop waits out a memory round trip per few elements), the stores are 16 bytes wide
+    // a thread's 16 outputs as 8 column pairs, 16-byte stores; twiddles from the ladder (N1 >= 8) or, for the two
+    // shortest sizes, 32 table entries all issued before the first product
     constexpr int PAIRS = TILE / 2 / THREADS;
-    float2 wc[2 * PAIRS], wf[2 * PAIRS];
+    float2 wa[LADDER ? 8 : 2 * PAIRS], wb[LADDER ? 8 : 2 * PAIRS];
+    if constexpr (LADDER) {
+        ladder_expand(la, wa);
+        ladder_expand(lb_, wb);
+    } else {
 #pragma unroll
-    for (int i = 0; i < PAIRS; ++i) {
-        const int e = 2 * (tid + i * THREADS), j = e >> LOG2C, c = e & (C - 1);
-        const uint32_t k1 = (uint32_t)rev_n1<LOG2N1>(j), n2 = (uint32_t)(tile * C + c);
-        const uint32_t m0 = (n2 * k1) & tw.bmask, m1 = ((n2 + 1u) * k1) & tw.bmask;
-        wc[2 * i] = tw.wc[m0 >> FBITS]; wf[2 * i] = tw.wf[m0 & ((1u << FBITS) - 1)];
-        wc[2 * i + 1] = tw.wc[m1 >> FBITS]; wf[2 * i + 1] = tw.wf[m1 & ((1u << FBITS) - 1)];
+        for (int i = 0; i < PAIRS; ++i) {
+            const int e = 2 * (tid + i * THREADS), j = e >> LOG2C, c = e & (C - 1);
+            const uint32_t k1 = (uint32_t)rev_n1<LOG2N1>(j), n2 = (uint32_t)(tile * C + c);
+            const uint32_t m0 = (n2 * k1) & tw.bmask, m1 = ((n2 + 1u) * k1) & tw.bmask;
+            wa[2 * i] = tw.wc[m0 >> FBITS]; wb[2 * i] = tw.wf[m0 & FMASK];
+            wa[2 * i + 1] = tw.wc[m1 >> FBITS]; wb[2 * i + 1] = tw.wf[m1 & FMASK];
+        }
     }
 #pragma unroll
     for (int i = 0; i < PAIRS; ++i) {
         const int e = 2 * (tid + i * THREADS), j = e >> LOG2C, c = e & (C - 1);
         const int k1 = rev_n1<LOG2N1>(j), n2 = tile * C + c;
         const float4 t = *reinterpret_cast<const float4 *>(T + e);
-        const float2 y0 = cmul(make_float2(t.x, t.y), cmul(wc[2 * i], wf[2 * i]));
-        const float2 y1 = cmul(make_float2(t.z, t.w), cmul(wc[2 * i + 1], wf[2 * i + 1]));
+        float2 y0, y1;
+        if constexpr (LADDER) {
+            y0 = cmul(make_float2(t.x, t.y), wa[i]);
+            y1 = cmul(make_float2(t.z, t.w), wb[i]);
+        } else {
+            y0 = cmul(make_float2(t.x, t.y), cmul(wa[2 * i], wb[2 * i]));
+            y1 = cmul(make_float2(t.z, t.w), cmul(wa[2 * i + 1], wb[2 * i + 1]));
+        }
         *reinterpret_cast<float4 *>(Yr + (size_t)k1 * N2 + n2) = make_float4(y0.x, y0.y, y1.x, y1.y);
     }
 }
@@ -150,7 +199,7 @@ struct LongPartial {
 // half is the zero pad the shift wrapped into) are quantised like cdsp::convto8bit (src/cdsp.cc:51-54) into the row at
 // out + blockIdx.y * B -- the cpacketize::write(complex<float>*) of src/cpacketizer.cc:158-172 for this mode.
 template <int LOG2N1, bool OUTPUT = false>
-__global__ __launch_bounds__(THREADS, 2) void k_long_inv_cols(const float2 *__restrict__ Z, LongTw tw, LongPartial *__restrict__ part, int8_t *__restrict__ out = nullptr)
+__global__ __launch_bounds__(THREADS, 4) void k_long_inv_cols(const float2 *__restrict__ Z, LongTw tw, LongPartial *__restrict__ part, int8_t *__restrict__ out = nullptr)
 {
     constexpr int N1 = 1 << LOG2N1, LOG2C = LOG2TILE - LOG2N1, C = 1 << LOG2C;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -160,29 +209,46 @@ __global__ __launch_bounds__(THREADS, 2) void k_long_inv_cols(const float2 *__re
     const size_t B = (size_t)N1 * N2;
     const float2 *Zr = Z + (size_t)blockIdx.y * B;
     {
-        // a thread's 16 inputs as 8 column pairs: every load (8 x 16 bytes of Z, 32 twiddle-table entries) is in
+        // a thread's 16 inputs as 8 column pairs: every load (8 x 16 bytes of Z, the twiddle-table entries) is in
         // flight before the first product -- in a rolled loop each few elements cost a memory round trip
         constexpr int PAIRS = TILE / 2 / THREADS;
+        constexpr bool LADDER = LOG2N1 >= 3;
         float4 z[PAIRS];
-        float2 wc[2 * PAIRS], wf[2 * PAIRS];
+        float2 wa[LADDER ? 8 : 2 * PAIRS], wb[LADDER ? 8 : 2 * PAIRS];
 #pragma unroll
         for (int i = 0; i < PAIRS; ++i) {
             const int e = 2 * (tid + i * THREADS), k1 = e >> LOG2C, c = e & (C - 1), n2 = tile * C + c;
             z[i] = *reinterpret_cast<const float4 *>(Zr + (size_t)k1 * N2 + n2);
         }
+        if constexpr (LADDER) {
+            constexpr int LOG2S = LOG2N1 - 3;
+            const uint32_t k0 = (uint32_t)(2 * tid) >> LOG2C, n2 = (uint32_t)(tile * C + ((2 * tid) & (C - 1)));
+            Ladder la, lb_;
+            ladder_issue(la, tw, n2, k0, 1u << LOG2S, 2u << LOG2S, 4u << LOG2S);
+            ladder_issue(lb_, tw, n2 + 1u, k0, 1u << LOG2S, 2u << LOG2S, 4u << LOG2S);
+            ladder_expand(la, wa);
+            ladder_expand(lb_, wb);
+        } else {
 #pragma unroll
-        for (int i = 0; i < PAIRS; ++i) {
-            const int e = 2 * (tid + i * THREADS);
-            const uint32_t k1 = (uint32_t)(e >> LOG2C), n2 = (uint32_t)(tile * C + (e & (C - 1)));
-            const uint32_t m0 = (n2 * k1) & tw.bmask, m1 = ((n2 + 1u) * k1) & tw.bmask;
-            wc[2 * i] = tw.wc[m0 >> FBITS]; wf[2 * i] = tw.wf[m0 & ((1u << FBITS) - 1)];
-            wc[2 * i + 1] = tw.wc[m1 >> FBITS]; wf[2 * i + 1] = tw.wf[m1 & ((1u << FBITS) - 1)];
+            for (int i = 0; i < PAIRS; ++i) {
+                const int e = 2 * (tid + i * THREADS);
+                const uint32_t k1 = (uint32_t)(e >> LOG2C), n2 = (uint32_t)(tile * C + (e & (C - 1)));
+                const uint32_t m0 = (n2 * k1) & tw.bmask, m1 = ((n2 + 1u) * k1) & tw.bmask;
+                wa[2 * i] = tw.wc[m0 >> FBITS]; wb[2 * i] = tw.wf[m0 & FMASK];
+                wa[2 * i + 1] = tw.wc[m1 >> FBITS]; wb[2 * i + 1] = tw.wf[m1 & FMASK];
+            }
         }
 #pragma unroll
         for (int i = 0; i < PAIRS; ++i) {
             const int e = 2 * (tid + i * THREADS);
-            const float2 y0 = cmulc(make_float2(z[i].x, z[i].y), cmul(wc[2 * i], wf[2 * i]));
-            const float2 y1 = cmulc(make_float2(z[i].z, z[i].w), cmul(wc[2 * i + 1], wf[2 * i + 1]));
+            float2 y0, y1;
+            if constexpr (LADDER) {
+                y0 = cmulc(make_float2(z[i].x, z[i].y), wa[i]);
+                y1 = cmulc(make_float2(z[i].z, z[i].w), wb[i]);
+            } else {
+                y0 = cmulc(make_float2(z[i].x, z[i].y), cmul(wa[2 * i], wb[2 * i]));
+                y1 = cmulc(make_float2(z[i].z, z[i].w), cmul(wa[2 * i + 1], wb[2 * i + 1]));
+            }
             *reinterpret_cast<float4 *>(T + e) = make_float4(y0.x, y0.y, y1.x, y1.y);
         }
     }
