@@ -228,12 +228,22 @@ def main():
     fence()
     # timed region: hipEvent pairs around the dominant kernel (K1) only -- every pair costs stream time.  The region of
     # exactly --steps steps is repeated and the MEDIAN reported: a 1 ms region between two device-wide fences is noise-prone
+    # How many repeats: a device that has idled (the seconds of host-side input generation above) needs ~50 ms of sustained
+    # load before its clocks settle -- measured r02, `region_ms` of a 60-repeat run: 1.17, 1.19, 1.28, 1.25, 1.20 ... 0.99 ms
+    # for the same 20 steps -- so 5 repeats of a 1 ms region all sat inside that ramp.  The region is now repeated until
+    # ~250 ms of timed work have run (5 .. 400 repeats) and the median is what a busy device sustains; `region_ms` carries the
+    # series, `value_first5` the median of the first five repeats (what r01 / early r02 records reported).
     nbatch = -(-args.steps // T)
-    est_ms = args.steps * 0.06 / world
-    repeats = args.repeats if args.repeats > 0 else (5 if est_ms < 50 else 1)
+    est_ms = args.steps * (0.55 if args.cfg5 else 0.05 * (nsig + 1) / 1025) / world
+    repeats = args.repeats if args.repeats > 0 else int(min(400, max(5, -(-250.0 // max(est_ms, 1e-3)))))
+    repeats = min(repeats, max(1, 4096 // nbatch))                    # one HIP-event pair per K1 launch
     plan.enable_profiling(min(max(nbatch * repeats, 1), 4096), 1 << b.KERNEL_XCORR_LAG)
     dts = [timed(args.steps) for _ in range(repeats)]
     dt = float(np.median(dts))
+    # the repeats whose time lies in the central half of the distribution: K1's average launch duration is taken over THEIR
+    # launches, so that `roofline` and `value` describe the same state of the device
+    order = np.argsort(dts)
+    central = sorted(int(i) for i in order[len(order) // 4: len(order) - len(order) // 4])
     # checked right here, before later (untimed) runs reuse the packet sets: the last full batch -- every packet this rank
     # assembled must hold every rank's rows under the header of the right block, and its scalars block every rank's lags
     assembled_ok = scalars_ok = True
@@ -289,7 +299,8 @@ def main():
     if rank == 0:
         A_block = nrows * B                                   # algorithmic bytes per block
         k1_all = k_ms["xcorr_lag"]
-        k1s = [x for i, x in enumerate(k1_all) if (i % nbatch) < full_batches] if full_batches else k1_all      # launches that carried T blocks
+        keep = set(central) if len(k1_all) == nbatch * repeats else set(range(repeats))
+        k1s = [x for i, x in enumerate(k1_all) if (i // nbatch) in keep and ((i % nbatch) < full_batches or not full_batches)]   # central repeats, launches that carried T blocks
         k1 = float(np.mean(k1s)) if len(k1s) else float("nan")
         tb = T if full_batches else args.steps
         k1_bytes = tb * slab.row_count * B                    # int8 bytes one K1 launch consumes (tb blocks)
@@ -299,6 +310,8 @@ def main():
             "metric": f"aligned IQ blocks/s ({nsig} ch x {L})", "value": blocks_per_s, "unit": "blocks/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
             "repeats": repeats, "value_spread": [args.steps / max(dts), args.steps / min(dts)],     # the region is timed `repeats` times: value = median
+            "region_ms": [round(1e3 * dts[i], 4) for i in sorted(set(np.linspace(0, len(dts) - 1, min(len(dts), 48)).astype(int).tolist()))],   # the series in order (evenly thinned to <= 48 entries)
+            "value_first5": args.steps / float(np.median(dts[:5])),                                  # a device just out of idle: the ramp (see the comment at `repeats`)
             "batches_timed": {"per_repeat": nbatch, "whole": full_batches, "ragged_blocks": args.steps - full_batches * T, "blocks_per_batch": T},
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{'cfg5' if args.cfg5 else {21: 'cfg2', 256: 'cfg3', 1024: 'cfg4'}.get(nsig, 'custom') if L == 8192 else 'custom'}: 1 ref + {nsig} signal rows x {L} int8 IQ samples per block, track cadence "
@@ -345,7 +358,8 @@ def main():
         # the rate is timed without per-kernel events over >= 16 batches (a batch is ~0.6 ms: a shorter region would
         # mostly measure its own fences); the kernel's launch duration comes from a separate short profiled run
         n_l = max(args.steps, 16 * T) // T * T
-        dt_l = timed(n_l, fl_locked)
+        dts_l = [timed(n_l, fl_locked) for _ in range(int(min(40, max(3, 100.0 // (n_l * 0.009)))))]     # ~100 ms of timed work, median (as `value`)
+        dt_l = float(np.median(dts_l))
         plan.enable_profiling(256, (1 << b.KERNEL_PHASE_DOT) | (1 << b.KERNEL_ALIGN_QUANT))
         run_steps(4 * T, fl_locked)
         fence()
