@@ -767,7 +767,7 @@ static int plan_init_state(crsdr_plan *p)
     HIP_TRY(hipMemset(p->d_lag_state, 0, sizeof(int32_t) * n));
     HIP_TRY(hipMemset(p->d_mag_state, 0, sizeof(float) * n));
     HIP_TRY(hipMemset(p->d_frac_state, 0, sizeof(float) * n));
-    HIP_TRY(hipMemset(p->d_corr, 0xFF, sizeof(long long) * 2 * n * T));
+    HIP_TRY(hipMemset(p->d_corr, 0xFF, sizeof(long long) * 4 * n * T));
     p->chain_armed[0] = p->chain_armed[1] = (int)T;
     p->phase_cur = 0;
     p->last_nblocks = 0;
@@ -861,7 +861,7 @@ static int plan_alloc(crsdr_plan *p)
     HIP_TRY(hipMalloc((void **)&p->d_mag, sizeof(float) * n * T * 2));
     HIP_TRY(hipMalloc((void **)&p->d_frac, sizeof(float) * n * T * 2));
     HIP_TRY(hipMalloc((void **)&p->d_phasor, sizeof(float2) * n * T));
-    HIP_TRY(hipMalloc((void **)&p->d_corr, sizeof(long long) * 2 * n * T));
+    HIP_TRY(hipMalloc((void **)&p->d_corr, sizeof(long long) * 4 * n * T));   // unit words, then chain values (k_align_fused)
     HIP_TRY(hipMalloc((void **)&p->d_sync, 64));
     HIP_TRY(hipMemset(p->d_sync, 0, 64));
     { const char *e = getenv("CRSDR_K2_FUSED"); if (e) p->fused_k2 = atoi(e) != 0; }
@@ -1281,12 +1281,14 @@ extern "C" int crsdr_plan_submit_batch(crsdr_plan *p, const void *rows, int mem_
         // many leading blocks of each slot are armed and falls back to a memset when a batch needs more than that
         const int cs = p->chain_slot;
         unsigned long long *chain = reinterpret_cast<unsigned long long *>(p->d_corr);
-        FusedSync fs{p->d_sync, p->d_sync + 1, chain + cs, aa.refnoise ? chain + (cs ^ 1) : nullptr, p->row_count, spin_limit};
+        unsigned long long *chainv = chain + 2 * n * (size_t)p->max_batch;      // second half of d_corr: the chain values, same two slots
+        FusedSync fs{p->d_sync, p->d_sync + 1, chain + cs, aa.refnoise ? chain + (cs ^ 1) : nullptr, chainv + cs, aa.refnoise ? chainv + (cs ^ 1) : nullptr,
+                     p->row_count, spin_limit};
         hipEvent_t *pe = prof_pair(p, CRSDR_KERNEL_ALIGN_QUANT);
         if (pe) HIP_TRY(hipEventRecord(pe[0], S));
         if (aa.refnoise) {
             if (nblocks > 1 && p->chain_armed[cs] < nblocks) {
-                HIP_TRY(hipMemsetAsync(p->d_corr, 0xFF, sizeof(long long) * 2 * n * T, S));
+                HIP_TRY(hipMemsetAsync(p->d_corr, 0xFF, sizeof(long long) * 4 * n * T, S));
                 p->chain_armed[0] = p->chain_armed[1] = (int)T;
             }
             p->chain_armed[cs] = 0;                                             // published into
@@ -1387,7 +1389,7 @@ static int check_fused_status(crsdr_plan *p)
                 (void)hipMemcpy(p->d_state, p->d_state_snap, p->state_bytes, hipMemcpyDeviceToDevice);
                 p->phase_cur = p->snap_phase_cur;
             }
-            (void)hipMemset(p->d_corr, 0xFF, sizeof(long long) * 2 * (size_t)p->nrows * (size_t)p->max_batch);
+            (void)hipMemset(p->d_corr, 0xFF, sizeof(long long) * 4 * (size_t)p->nrows * (size_t)p->max_batch);
             p->chain_armed[0] = p->chain_armed[1] = p->max_batch;
             p->snap_valid = false; p->k1_used = false; p->q_disabled = true; p->submitted = false;
             return fail(CRSDR_EHIP, "xcorr: %d workgroup(s) of the two-row kernel ran out of a bounded wait; the batches submitted since the last "

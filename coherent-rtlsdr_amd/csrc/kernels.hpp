@@ -363,8 +363,11 @@ __device__ __forceinline__ uint32_t rotq_word(uint32_t s, float2 p)
         asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1]" : "=v"(y) : "v"(t1), "v"(t2));                                    // (I px - Q py, Q px + I py)
         y = y * 127.0f;
         // round first, then let v_cvt_pk_u8_f32 saturate: rint(clamp(x)) == clamp(rint(x)) on [-128, 127] (ties to even keep
-        // 127.5 -> 128 -> 127 and -128.5 -> -128), and r + 128 is exact, so the explicit clamp of cdsp::convto8bit is implied
-        const c2 u = c2{rintf(y.x), rintf(y.y)} + 128.0f;
+        // 127.5 -> 128 -> 127 and -128.5 -> -128), and r + 128 is exact, so the explicit clamp of cdsp::convto8bit is implied.
+        // rintf for both halves in ONE packed add: |y| < 2^22, so y + 1.5 * 2^23 lands where the spacing is 1 and its own
+        // round-to-nearest-even IS rintf(y) (the constant is even: ties fall on the same parity); taking 1.5 * 2^23 - 128
+        // off again is exact and leaves rintf(y) + 128.  (-1 instruction per sample against v_rndne x 2 + one add.)
+        const c2 u = (y + 12582912.0f) - 12582784.0f;
         // byte 0 first: its "old" operand may be anything (all four bytes get written), so no zero has to be materialised
         if (h == 0) asm("v_cvt_pk_u8_f32 %0, %1, 0, %1" : "=v"(out) : "v"(u.x));
         else asm("v_cvt_pk_u8_f32 %0, %1, %2, %0" : "+v"(out) : "v"(u.x), "n"(2 * h));
@@ -504,6 +507,8 @@ struct FusedSync {
     unsigned int *status;              // [0] number of look-back waits that ran out and were computed locally
     unsigned long long *chain;         // [T][nrows] at stride 2: this batch's unit phasor bits, all-ones = not yet
     unsigned long long *rearm;         // the other slot of the same entries: reset to all-ones for the next batch (or null)
+    unsigned long long *chainv;        // [T][nrows] at stride 2: the CHAIN value (phasor after block t) once a workgroup has folded it; all-ones = not yet
+    unsigned long long *rearmv;        // its other slot, re-armed like `rearm`
     int row_count;
     int spin_limit;                    // polls before the local fallback (kFusedSpinLimit); < 0: treat every earlier block as missing (tests)
 };
@@ -520,6 +525,7 @@ __global__ __launch_bounds__(kAlignThreads, 8) void k_align_fused(AlignArgs a_, 
     __shared__ long long sred[2 * (kAlignThreads / 64)];
     __shared__ float2 sp;
     __shared__ unsigned long long smiss, sfix[64];
+    __shared__ int sstar;
     const int tid = threadIdx.x;
     const unsigned int per = (unsigned)fs.row_count + 1u;
     const unsigned int ticket = blockIdx.x;
@@ -604,11 +610,14 @@ __global__ __launch_bounds__(kAlignThreads, 8) void k_align_fused(AlignArgs a_, 
     // this row have already published -- so that their latency hides behind the row loads instead of following them
     float2 p_in = make_float2(0.f, 0.f);
     unsigned long long bits = 0ull;          // wave 0, lane u <= t: unit phasor of block u of this row
+    unsigned long long cv = kChainEmpty;     // wave 0, lane u < t: the chain value after block u, where its workgroup has got that far
     if (tid < 64) {
         p_in = a.phase_in[row];
-        if (a.refnoise && tid < t)
+        if (a.refnoise && tid < t) {
             bits = fs.spin_limit < 0 ? kChainEmpty
                                      : __hip_atomic_load(fs.chain + 2 * ((size_t)tid * a.nrows + row), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (fs.spin_limit >= 0) cv = __hip_atomic_load(fs.chainv + 2 * ((size_t)tid * a.nrows + row), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
     }
 #pragma unroll
     for (int q = 0; q < 4; ++q) sv[q] = make_uint4(sv[q].x ^ a.xor80, sv[q].y ^ a.xor80, sv[q].z ^ a.xor80, sv[q].w ^ a.xor80);
@@ -652,21 +661,32 @@ __global__ __launch_bounds__(kAlignThreads, 8) void k_align_fused(AlignArgs a_, 
                 if (fs.rearm) fs.rearm[2 * o] = kChainEmpty;    // nobody reads this slot before the next launch
             }
             // lane u < t holds the unit phasor of block u (published right after that block's dot product, long
-            // before its own rotation) from the prefetch above, or polls for it now; lane t takes this block's
-            if (tid < t) {
-                unsigned long long *src = fs.chain + 2 * ((size_t)tid * a.nrows + row);
+            // before its own rotation) and, where block u's workgroup has already folded it, the CHAIN value after block
+            // u, both from the prefetch above.  The fold starts from the latest chain value there is (block ustar; the
+            // carried phasor if none) and needs the unit phasors of the blocks after it only: those are polled for.
+            // The chain value is bit for bit what folding from the carried phasor gives, so the start point changes
+            // nothing but the length of the fold (t + 1 steps at first: 8 % of the kernel's VALU work at T = 64).
+            int ustar = -1;
+            {
+                const unsigned long long *srcu = fs.chain + 2 * ((size_t)tid * a.nrows + row);
+                const unsigned long long *srcv = fs.chainv + 2 * ((size_t)tid * a.nrows + row);
                 int spins = 0;
-                while (bits == kChainEmpty && spins < fs.spin_limit) {
-                    bits = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if (bits == kChainEmpty) __builtin_amdgcn_s_sleep(8);
+                for (;;) {
+                    const unsigned long long have = __ballot(tid < t && cv != kChainEmpty);
+                    ustar = have ? 63 - __builtin_clzll(have) : -1;
+                    const bool need = tid < t && tid > ustar && bits == kChainEmpty;
+                    if (!__ballot(need) || spins >= fs.spin_limit) break;
+                    if (need) bits = __hip_atomic_load(srcu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (tid < t && tid > ustar && cv == kChainEmpty) cv = __hip_atomic_load(srcv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __builtin_amdgcn_s_sleep(8);
                     ++spins;
                 }
             }
             const unsigned long long own = __shfl(mine, 0, 64);
             if (tid == t) bits = own;
-            const unsigned long long missing = __ballot(tid < t && bits == kChainEmpty);
-            if (tid == 0) smiss = missing;
-        } else if (tid == 0) smiss = 0ull;
+            const unsigned long long missing = __ballot(tid < t && tid > ustar && bits == kChainEmpty);
+            if (tid == 0) { smiss = missing; sstar = ustar; }
+        } else if (tid == 0) { smiss = 0ull; sstar = -1; }
     }
     __syncthreads();
     // Fallback, normally never taken: an earlier block's workgroup has not published within the poll budget (its
@@ -707,9 +727,15 @@ __global__ __launch_bounds__(kAlignThreads, 8) void k_align_fused(AlignArgs a_, 
     if (tid < 64) {
         float2 p = p_in;
         if (a.refnoise) {
-            if (tid < t && bits == kChainEmpty) bits = sfix[tid];
+            const int ustar = sstar;           // wave-uniform: the block whose chain value the fold starts from (-1: the carried phasor)
+            if (tid < t && tid > ustar && bits == kChainEmpty) bits = sfix[tid];
+            if (ustar >= 0) {
+                const unsigned sl = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(cv & 0xffffffffull), ustar),
+                               sh = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(cv >> 32), ustar);
+                p = make_float2(__uint_as_float(sl), __uint_as_float(sh));
+            }
             const int blo = (int)(unsigned)(bits & 0xffffffffull), bhi = (int)(unsigned)(bits >> 32);
-            for (int u = 0; u <= t; ++u) {     // one sequential fold in block order (src/csdrdevice.cc:66-67)
+            for (int u = ustar + 1; u <= t; ++u) {     // one sequential fold in block order (src/csdrdevice.cc:66-67)
                 // u is wave-uniform: v_readlane into scalar registers, not a trip through the LDS crossbar
                 const unsigned rl = (unsigned)__builtin_amdgcn_readlane(blo, u), rh = (unsigned)__builtin_amdgcn_readlane(bhi, u);
                 if ((rl | rh) != 0u) {
@@ -723,6 +749,12 @@ __global__ __launch_bounds__(kAlignThreads, 8) void k_align_fused(AlignArgs a_, 
             a.phasor[o] = p;                                    // get_phasecorrect() after block t
             if (t == a.nblocks - 1) a.phase_out[row] = p;       // state carried to the next batch
             sp = p;
+            if (a.refnoise) {                                   // later blocks of this row may start their fold here
+                if (t < a.nblocks - 1)
+                    __hip_atomic_store(fs.chainv + 2 * o, (unsigned long long)__float_as_uint(p.x) | ((unsigned long long)__float_as_uint(p.y) << 32),
+                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (fs.rearmv) fs.rearmv[2 * o] = kChainEmpty;
+            }
         }
     }
     __syncthreads();

@@ -53,10 +53,11 @@ def child(track):
     batch(0, fl)
     out = plan.fetch(want_packet=False)
     assert np.array_equal(out["lag"][1:], params.d)
-    for i in range(4):
+    # a device just out of idle needs ~40 ms of load before its clocks settle (bench.py, `region_ms`): warm up for ~100 ms
+    for i in range(32 if track else 200):
         batch(i, fl_run)
     torch.cuda.synchronize()
-    n = 8 if track else 24
+    n = 16 if track else 64
     plan.enable_profiling(n, 0xF)
     t0 = time.perf_counter()
     for i in range(n):
