@@ -321,6 +321,26 @@ static hipError_t launch_op_fft(hipStream_t s, int howmany, float2 *out, const f
         }                                                                               \
     }()
 
+// column passes of the long-block path: persistent workgroups, two per CU (64 KiB tiles), each walking its share of the
+// (row, tile) work items with the next item's loads in flight (longblock.hpp); CRSDR_LONG_PERSIST=0: one workgroup per item
+static int lb_grid(int nwork, bool stage_c = false)
+{
+    static const int per_cu_a = [] { const char *e = getenv("CRSDR_LONG_PERSIST"); return e ? atoi(e) : 2; }();
+    // stage C (reads only) is better off with one workgroup per item: measured r02, cfg5, per launch of 10.5 rows: 55 us against
+    // 61 us persistent (its reads alone run at 4.1 TB/s either way: 43 us); stage A (mostly stores) gains: 61 -> 52 us
+    static const int per_cu_c = [] { const char *e = getenv("CRSDR_LONG_PERSIST_C"); return e ? atoi(e) : 0; }();
+    const int per_cu = stage_c ? per_cu_c : per_cu_a;
+    static const int cus = [] {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 1) n = 256;
+        return n;
+    }();
+#ifdef CRSDR_LB_EXPERIMENT
+    static const int dbg_set = [] { const char *e = getenv("CRSDR_LB_DBG"); int v = e ? atoi(e) : 0; (void)hipMemcpyToSymbol(HIP_SYMBOL(lb::lb_dbg), &v, sizeof(v)); return v; }();
+    (void)dbg_set;
+#endif
+    return per_cu > 0 ? std::max(1, std::min(nwork, per_cu * cus)) : nwork;
+}
 template <int LOG2N1, bool IS_REF>
 static hipError_t launch_long_fwd_cols(hipStream_t s, int nrows_launch, const int8_t *rows, int row_begin, uint32_t xor80,
                                        const lb::LongTw &tw, float2 *Y)
@@ -328,7 +348,8 @@ static hipError_t launch_long_fwd_cols(hipStream_t s, int nrows_launch, const in
     auto kern = lb::k_long_fwd_cols<LOG2N1, IS_REF>;
     hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lb::LDS_BYTES);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(kern, dim3(lb::ntiles(LOG2N1), nrows_launch), dim3(lb::THREADS), lb::LDS_BYTES, s, rows, row_begin, xor80, tw, Y);
+    const int nwork = lb::ntiles(LOG2N1) * nrows_launch;
+    hipLaunchKernelGGL(kern, dim3((unsigned)lb_grid(nwork)), dim3(lb::THREADS), lb::LDS_BYTES, s, rows, row_begin, xor80, tw, Y, nwork);
     return hipGetLastError();
 }
 // stage B with two lines per CU in opposite phases (k_rows14_cf32q): a line's HBM phases run beside the other line's transforms
@@ -389,7 +410,8 @@ static hipError_t launch_long_out_cols(hipStream_t s, int nrows_launch, const fl
     auto kern = lb::k_long_inv_cols<LOG2N1, true>;
     hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lb::LDS_BYTES);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(kern, dim3(lb::ntiles(LOG2N1), nrows_launch), dim3(lb::THREADS), lb::LDS_BYTES, s, Z, tw, (lb::LongPartial *)nullptr, out);
+    const int nwork = lb::ntiles(LOG2N1) * nrows_launch;
+    hipLaunchKernelGGL(kern, dim3((unsigned)lb_grid(nwork)), dim3(lb::THREADS), lb::LDS_BYTES, s, Z, tw, (lb::LongPartial *)nullptr, out, nwork);
     return hipGetLastError();
 }
 template <int LOG2N1>
@@ -398,7 +420,8 @@ static hipError_t launch_long_inv_cols(hipStream_t s, int nrows_launch, const fl
     auto kern = lb::k_long_inv_cols<LOG2N1>;
     hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lb::LDS_BYTES);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(kern, dim3(lb::ntiles(LOG2N1), nrows_launch), dim3(lb::THREADS), lb::LDS_BYTES, s, Z, tw, part, (int8_t *)nullptr);
+    const int nwork = lb::ntiles(LOG2N1) * nrows_launch;
+    hipLaunchKernelGGL(kern, dim3((unsigned)lb_grid(nwork, true)), dim3(lb::THREADS), lb::LDS_BYTES, s, Z, tw, part, (int8_t *)nullptr, nwork);
     return hipGetLastError();
 }
 
@@ -1183,13 +1206,26 @@ extern "C" int crsdr_plan_submit_batch(crsdr_plan *p, const void *rows, int mem_
         // B = N1 x 16384: column FFTs -> row FFTs (x conj ref, inverse) -> inverse column FFTs + argmax -> finalize
         lb::LongTw tw{p->d_wc, p->d_wf, p->d_tw1, p->d_tw, (uint32_t)(p->B - 1)};
         const int n1 = 1 << p->log2n1, l1 = p->log2n1;
+        // The reference row's two stages (one row: 256 tiles, 128 lines -- they cannot fill the device) run on the aux stream
+        // into the other spectrum slot, like K0 of the short blocks: with resident input they sit under the previous block's
+        // stage C and phase kernels instead of in front of this block's stage A (21 us of 521 per cfg5 block).  The work line
+        // d_Yref is only touched on the aux stream; a slot is rewritten after the last stage B that read it (ev_k1done).
+        const int slot = (p->slot ^= 1);
+        const bool forked = !input_ready || d_readcnt || d_mask;
+        if (forked) {
+            HIP_TRY(hipEventRecord(p->ev_fork, S));
+            if (!input_ready) HIP_TRY(hipStreamWaitEvent(A, p->ev_fork, 0));
+        }
+        if (p->k1done_valid[slot]) HIP_TRY(hipStreamWaitEvent(A, p->ev_k1done[slot], 0));
         hipEvent_t *pe0 = prof_pair(p, CRSDR_KERNEL_REF_SPECTRUM);
-        if (pe0) HIP_TRY(hipEventRecord(pe0[0], S));
-        HIP_TRY(CRSDR_DISPATCH_N1(l1, (launch_long_fwd_cols<LG, true>(S, 1, d_in, 0, xor80, tw, p->d_Yref))));
-        HIP_TRY(launch_long_rows<true>(S, n1, 1, p->d_Yref, p->d_twA, p->d_twB, p->d_refspec[0]));
-        if (pe0) HIP_TRY(hipEventRecord(pe0[1], S));
+        if (pe0) HIP_TRY(hipEventRecord(pe0[0], A));
+        HIP_TRY(CRSDR_DISPATCH_N1(l1, (launch_long_fwd_cols<LG, true>(A, 1, d_in, 0, xor80, tw, p->d_Yref))));
+        HIP_TRY(launch_long_rows<true>(A, n1, 1, p->d_Yref, p->d_twA, p->d_twB, p->d_refspec[slot]));
+        if (pe0) HIP_TRY(hipEventRecord(pe0[1], A));
+        HIP_TRY(hipEventRecord(p->ev_ref[slot], A));
+        HIP_TRY(hipStreamWaitEvent(S, p->ev_ref[slot], 0));
         XcorrArgs xa;
-        xa.rows = d_in; xa.block_stride = d_stride; xa.refspec = p->d_refspec[0]; xa.lag_mask = d_mask;
+        xa.rows = d_in; xa.block_stride = d_stride; xa.refspec = p->d_refspec[slot]; xa.lag_mask = d_mask;
         xa.row_begin = p->row_begin; xa.nrows = p->nrows; xa.nblocks = 1; xa.xor80 = xor80; xa.stagger = 0;
         xa.lag = o_lag; xa.mag = o_mag; xa.frac = o_frac;
         xa.lag_state = p->d_lag_state; xa.mag_state = p->d_mag_state; xa.frac_state = p->d_frac_state;
@@ -1209,12 +1245,14 @@ extern "C" int crsdr_plan_submit_batch(crsdr_plan *p, const void *rows, int mem_
                     p->snap_valid = true; p->snap_phase_cur = p->phase_cur;
                     HIP_TRY(hipMemcpyAsync(p->d_state_snap, p->d_state, p->state_bytes, hipMemcpyDeviceToDevice, S));
                 }
-                HIP_TRY(launch_long_rows_q(S, n1, cnt, Yc, p->d_twA, p->d_twB, p->d_refspec[0], reinterpret_cast<int *>(p->d_sync + 2), p->d_sync + 3, &p->q_work_base));
+                HIP_TRY(launch_long_rows_q(S, n1, cnt, Yc, p->d_twA, p->d_twB, p->d_refspec[slot], reinterpret_cast<int *>(p->d_sync + 2), p->d_sync + 3, &p->q_work_base));
                 p->k1_used = true;
             } else
-                HIP_TRY(launch_long_rows<false>(S, n1, cnt, Yc, p->d_twA, p->d_twB, p->d_refspec[0]));
+                HIP_TRY(launch_long_rows<false>(S, n1, cnt, Yc, p->d_twA, p->d_twB, p->d_refspec[slot]));
             HIP_TRY(CRSDR_DISPATCH_N1(l1, (launch_long_inv_cols<LG>(S, cnt, Yc, tw, p->d_part + (size_t)r0 * lb::ntiles(l1)))));
         }
+        HIP_TRY(hipEventRecord(p->ev_k1done[slot], S));       // the last reader of this block's reference spectrum has been enqueued
+        p->k1done_valid[slot] = true;
         hipLaunchKernelGGL(lb::k_long_finalize, dim3(p->row_count), dim3(256), 0, S, p->d_Y, p->d_part, tw, n1, lb::ntiles(l1), xa);
         HIP_TRY(hipGetLastError());
         if (pe1) HIP_TRY(hipEventRecord(pe1[1], S));

@@ -31,6 +31,12 @@ __host__ __device__ constexpr int ntiles(int log2n1) { return 1 << (LOG2N2 + log
 constexpr int FBITS = 11;                                                    // fine twiddle table: 2^11 entries
 constexpr size_t LDS_BYTES = sizeof(float2) * TILE + 512;
 
+#ifdef CRSDR_LB_EXPERIMENT       // diagnostics only (a -DCRSDR_LB_EXPERIMENT build under tools/): bit 0 no transforms / reduction in stage C,
+__device__ int lb_dbg = 0;       // bit 1 XCD-contiguous tile order, bit 2 stage A without transforms
+#define LB_DBG(bit) (lb_dbg & (bit))
+#else
+#define LB_DBG(bit) 0
+#endif
 struct LongTw {
     const float2 *wc;  // W_B^(i << FBITS), i < B >> FBITS      (coarse)
     const float2 *wf;  // W_B^j,            j < 1 << FBITS      (fine)
@@ -69,8 +75,29 @@ __device__ __forceinline__ void col_fft(float2 *T, const float2 *__restrict__ tw
             for (int i = 0; i < R; ++i) v[i] = T[base + ((i << LM) << LOG2C)];
             dft<R, DIR>(v);
             if constexpr (M > 1) {
+                if constexpr (LOG2C >= 6) {
+                    // a wave sweeps the C >= 64 columns of ONE tile row group: n2 is wave-uniform, so the twiddles are scalar
+                    // loads into SGPRs.  That is more than cheaper: a VECTOR load here would be waited for with vmcnt, and
+                    // vector loads return in order -- the persistent column kernels' prefetch of the next tile (issued just
+                    // before these transforms) would have to land first.
+                    // (the table is read through a constant-address-space pointer: only then does the compiler take the uniform
+                    // address to the scalar unit -- through a plain global pointer it issued one vector load per twiddle and
+                    // waited for each, vmcnt(0), before the product)
+                    typedef const float __attribute__((address_space(4))) *ctab_t;
+                    const ctab_t tc = (ctab_t)(uintptr_t)tw1;
+                    const int n2u = __builtin_amdgcn_readfirstlane(n2);
+                    float2 wk[R];
 #pragma unroll
-                for (int k = 1; k < R; ++k) v[k] = ctw<DIR>(v[k], tw1[(n2 * k) << (4 * P)]);
+                    for (int k = 1; k < R; ++k) {
+                        const int o = 2 * ((n2u * k) << (4 * P));
+                        wk[k] = make_float2(tc[o], tc[o + 1]);
+                    }
+#pragma unroll
+                    for (int k = 1; k < R; ++k) v[k] = ctw<DIR>(v[k], wk[k]);
+                } else {
+#pragma unroll
+                    for (int k = 1; k < R; ++k) v[k] = ctw<DIR>(v[k], tw1[(n2 * k) << (4 * P)]);
+                }
             }
 #pragma unroll
             for (int i = 0; i < R; ++i) T[base + ((i << LM) << LOG2C)] = v[i];
@@ -107,82 +134,110 @@ __device__ __forceinline__ void ladder_expand(const Ladder &l, float2 *w)
 }
 
 // ---- A: int8 -> column FFTs -> x W_B^(n2 k1) -> Y[k1][n2] -------------------------------------------
-// grid (ntiles, rows); tile = columns [tile*C, (tile+1)*C), C = TILE / N1.  Signal rows carry samples at n < L
-// (n1 < N1/2), the ref row at n >= L (src/crtlsdr.cc:205-207,215-218).
+// Work item w = (row w / ntiles, tile w % ntiles); tile = columns [tile*C, (tile+1)*C), C = TILE / N1.  Signal rows carry
+// samples at n < L (n1 < N1/2), the ref row at n >= L (src/crtlsdr.cc:205-207,215-218).
+// Persistent form: the grid is two workgroups per CU (what the 64 KiB tiles allow) and a workgroup walks items w, w + grid, ...
+// with the NEXT item's loads (int8 words, twiddle-table entries) issued before the column transforms of the current one, and
+// the current item's 64 KiB of stores draining under the next item's loads and transforms -- a one-shot workgroup pays its
+// load latency, its transforms and its store drain one after the other before the CU slot sees the next tile.
 template <int LOG2N1, bool IS_REF>
 __global__ __launch_bounds__(THREADS, 4) void k_long_fwd_cols(const int8_t *__restrict__ rows, int row_begin, uint32_t xor80,
-                                                           LongTw tw, float2 *__restrict__ Y)
+                                                           LongTw tw, float2 *__restrict__ Y, int nwork)
 {
     constexpr int N1 = 1 << LOG2N1, LOG2C = LOG2TILE - LOG2N1, C = 1 << LOG2C, H = N1 / 2;
+    constexpr int LOG2NT = LOG2N2 + LOG2N1 - LOG2TILE, NT = 1 << LOG2NT;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float2 *T = reinterpret_cast<float2 *>(smem);
-    const int tid = threadIdx.x, tile = blockIdx.x;
+    const int tid0 = threadIdx.x;
     const size_t B = (size_t)N1 * N2;
-    const int row = IS_REF ? 0 : row_begin + (int)blockIdx.y;
-    const uint32_t *src = reinterpret_cast<const uint32_t *>(rows + (size_t)row * B); // word = 2 samples
     // non-zero half: H tile rows of C samples; the other H rows are zero
     constexpr int WORDS = H * C / 2 / THREADS;     // = TILE / 4 / THREADS input words per thread, all loaded before the first use
-    uint32_t u[WORDS];
-#pragma unroll
-    for (int i = 0; i < WORDS; ++i) {
-        const int w = tid + i * THREADS, n1 = (2 * w) >> LOG2C, c = (2 * w) & (C - 1);
-        u[i] = src[((size_t)n1 * N2 + (size_t)tile * C + c) >> 1];
-    }
-    // the output twiddles' table entries: issued with the input loads, used after the column transforms
     constexpr bool LADDER = LOG2N1 >= 3;
+    constexpr int LOG2S = LADDER ? LOG2N1 - 3 : 0;                   // a thread's tile rows: j0 + (i << LOG2S)
+    uint32_t u[WORDS];
     Ladder la, lb_;
-    if constexpr (LADDER) {
-        constexpr int LOG2S = LOG2N1 - 3;                        // a thread's tile rows: j0 + (i << LOG2S)
-        const uint32_t j0 = (uint32_t)(2 * tid) >> LOG2C, n2 = (uint32_t)(tile * C + ((2 * tid) & (C - 1)));
-        const uint32_t k0 = (uint32_t)rev_n1<LOG2N1>((int)j0);
-        constexpr uint32_t ks0 = (uint32_t)digit_reverse_c<LOG2N1>(1 << LOG2S), ks1 = (uint32_t)digit_reverse_c<LOG2N1>(2 << LOG2S),
-                           ks2 = (uint32_t)digit_reverse_c<LOG2N1>(4 << LOG2S);
-        ladder_issue(la, tw, n2, k0, ks0, ks1, ks2);
-        ladder_issue(lb_, tw, n2 + 1u, k0, ks0, ks1, ks2);
-    }
+    // the loads of one work item: its int8 words and the table entries of its output twiddles (used after the column transforms)
+    auto issue_words = [&](int w, int tid) {
+        const int tile = w & (NT - 1), row = IS_REF ? 0 : row_begin + (w >> LOG2NT);
+        const uint32_t *src = reinterpret_cast<const uint32_t *>(rows + (size_t)row * B); // word = 2 samples
 #pragma unroll
-    for (int i = 0; i < WORDS; ++i) {
-        const int w = tid + i * THREADS, n1 = (2 * w) >> LOG2C, c = (2 * w) & (C - 1);
-        const uint32_t x = u[i] ^ xor80;
-        const int r = IS_REF ? n1 + H : n1;
-        *reinterpret_cast<float4 *>(T + (r << LOG2C) + c) =
-            make_float4(i8_to_f32(sext8(x, 0)), i8_to_f32(sext8(x, 1)), i8_to_f32(sext8(x, 2)), i8_to_f32(sext8(x, 3)));
-    }
-    for (int e = tid; e < H * C; e += THREADS) T[((IS_REF ? 0 : H) << LOG2C) + e] = make_float2(0.f, 0.f);
-    __syncthreads();
-    col_fft<LOG2N1, -1>(T, tw.tw1, tid);
-    float2 *Yr = Y + (size_t)(IS_REF ? 0 : blockIdx.y) * B;
-    // a thread's 16 outputs as 8 column pairs, 16-byte stores; twiddles from the ladder (N1 >= 8) or, for the two
-    // shortest sizes, 32 table entries all issued before the first product
-    constexpr int PAIRS = TILE / 2 / THREADS;
-    float2 wa[LADDER ? 8 : 2 * PAIRS], wb[LADDER ? 8 : 2 * PAIRS];
-    if constexpr (LADDER) {
-        ladder_expand(la, wa);
-        ladder_expand(lb_, wb);
-    } else {
+        for (int i = 0; i < WORDS; ++i) {
+            const int x = tid + i * THREADS, n1 = (2 * x) >> LOG2C, c = (2 * x) & (C - 1);
+            u[i] = src[((size_t)n1 * N2 + (size_t)tile * C + c) >> 1];
+        }
+    };
+    auto issue_ladder = [&](int w, int tid) {
+        const int tile = w & (NT - 1);
+        if constexpr (LADDER) {
+            const uint32_t j0 = (uint32_t)(2 * tid) >> LOG2C, n2 = (uint32_t)(tile * C + ((2 * tid) & (C - 1)));
+            const uint32_t k0 = (uint32_t)rev_n1<LOG2N1>((int)j0);
+            constexpr uint32_t ks0 = (uint32_t)digit_reverse_c<LOG2N1>(1 << LOG2S), ks1 = (uint32_t)digit_reverse_c<LOG2N1>(2 << LOG2S),
+                               ks2 = (uint32_t)digit_reverse_c<LOG2N1>(4 << LOG2S);
+            ladder_issue(la, tw, n2, k0, ks0, ks1, ks2);
+            ladder_issue(lb_, tw, n2 + 1u, k0, ks0, ks1, ks2);
+        }
+    };
+    int w = blockIdx.x;
+    if (w >= nwork) return;
+    issue_words(w, tid0);
+    issue_ladder(w, tid0);
+    for (;;) {
+        // opaque per iteration: otherwise every LDS / global offset derived from the thread index is hoisted out of the item
+        // loop and kept (spilled) across it -- the one-shot form of this kernel needed 82 registers, the loop 128 + 53 spills
+        int tid = tid0;
+        asm volatile("" : "+v"(tid));
+        const int tile = w & (NT - 1);
+#pragma unroll
+        for (int i = 0; i < WORDS; ++i) {
+            const int xw = tid + i * THREADS, n1 = (2 * xw) >> LOG2C, c = (2 * xw) & (C - 1);
+            const uint32_t x = u[i] ^ xor80;
+            const int r = IS_REF ? n1 + H : n1;
+            *reinterpret_cast<float4 *>(T + (r << LOG2C) + c) =
+                make_float4(i8_to_f32(sext8(x, 0)), i8_to_f32(sext8(x, 1)), i8_to_f32(sext8(x, 2)), i8_to_f32(sext8(x, 3)));
+        }
+        for (int e = tid; e < H * C; e += THREADS) T[((IS_REF ? 0 : H) << LOG2C) + e] = make_float2(0.f, 0.f);
+        // a thread's 16 outputs as 8 column pairs, 16-byte stores; twiddles from the ladder (N1 >= 8) or, for the two
+        // shortest sizes, 32 table entries all issued before the first product
+        constexpr int PAIRS = TILE / 2 / THREADS;
+        float2 wa[LADDER ? 8 : 2 * PAIRS], wb[LADDER ? 8 : 2 * PAIRS];
+        __syncthreads();
+        const int wn = w + (int)gridDim.x;
+        if (wn < nwork) issue_words(wn, tid);                                // in flight during the column transforms
+        if (!LB_DBG(4)) col_fft<LOG2N1, -1>(T, tw.tw1, tid);
+        float2 *Yr = Y + (size_t)(IS_REF ? 0 : (w >> LOG2NT)) * B;
+        if constexpr (LADDER) {
+            ladder_expand(la, wa);
+            ladder_expand(lb_, wb);
+            if (wn < nwork) issue_ladder(wn, tid);                           // the next item's table entries: used after ITS column transforms
+        }
+        if constexpr (!LADDER) {
+#pragma unroll
+            for (int i = 0; i < PAIRS; ++i) {
+                const int e = 2 * (tid + i * THREADS), j = e >> LOG2C, c = e & (C - 1);
+                const uint32_t k1 = (uint32_t)rev_n1<LOG2N1>(j), n2 = (uint32_t)(tile * C + c);
+                const uint32_t m0 = (n2 * k1) & tw.bmask, m1 = ((n2 + 1u) * k1) & tw.bmask;
+                wa[2 * i] = tw.wc[m0 >> FBITS]; wb[2 * i] = tw.wf[m0 & FMASK];
+                wa[2 * i + 1] = tw.wc[m1 >> FBITS]; wb[2 * i + 1] = tw.wf[m1 & FMASK];
+            }
+        }
 #pragma unroll
         for (int i = 0; i < PAIRS; ++i) {
             const int e = 2 * (tid + i * THREADS), j = e >> LOG2C, c = e & (C - 1);
-            const uint32_t k1 = (uint32_t)rev_n1<LOG2N1>(j), n2 = (uint32_t)(tile * C + c);
-            const uint32_t m0 = (n2 * k1) & tw.bmask, m1 = ((n2 + 1u) * k1) & tw.bmask;
-            wa[2 * i] = tw.wc[m0 >> FBITS]; wb[2 * i] = tw.wf[m0 & FMASK];
-            wa[2 * i + 1] = tw.wc[m1 >> FBITS]; wb[2 * i + 1] = tw.wf[m1 & FMASK];
+            const int k1 = rev_n1<LOG2N1>(j), n2 = tile * C + c;
+            const float4 t = *reinterpret_cast<const float4 *>(T + e);
+            float2 y0, y1;
+            if constexpr (LADDER) {
+                y0 = cmul(make_float2(t.x, t.y), wa[i]);
+                y1 = cmul(make_float2(t.z, t.w), wb[i]);
+            } else {
+                y0 = cmul(make_float2(t.x, t.y), cmul(wa[2 * i], wb[2 * i]));
+                y1 = cmul(make_float2(t.z, t.w), cmul(wa[2 * i + 1], wb[2 * i + 1]));
+            }
+            *reinterpret_cast<float4 *>(Yr + (size_t)k1 * N2 + n2) = make_float4(y0.x, y0.y, y1.x, y1.y);
         }
-    }
-#pragma unroll
-    for (int i = 0; i < PAIRS; ++i) {
-        const int e = 2 * (tid + i * THREADS), j = e >> LOG2C, c = e & (C - 1);
-        const int k1 = rev_n1<LOG2N1>(j), n2 = tile * C + c;
-        const float4 t = *reinterpret_cast<const float4 *>(T + e);
-        float2 y0, y1;
-        if constexpr (LADDER) {
-            y0 = cmul(make_float2(t.x, t.y), wa[i]);
-            y1 = cmul(make_float2(t.z, t.w), wb[i]);
-        } else {
-            y0 = cmul(make_float2(t.x, t.y), cmul(wa[2 * i], wb[2 * i]));
-            y1 = cmul(make_float2(t.z, t.w), cmul(wa[2 * i + 1], wb[2 * i + 1]));
-        }
-        *reinterpret_cast<float4 *>(Yr + (size_t)k1 * N2 + n2) = make_float4(y0.x, y0.y, y1.x, y1.y);
+        if (wn >= nwork) break;
+        w = wn;
+        __syncthreads();                                // every thread has read its outputs from the tile: the next item may fill it
     }
 }
 
@@ -199,95 +254,124 @@ struct LongPartial {
 // half is the zero pad the shift wrapped into) are quantised like cdsp::convto8bit (src/cdsp.cc:51-54) into the row at
 // out + blockIdx.y * B -- the cpacketize::write(complex<float>*) of src/cpacketizer.cc:158-172 for this mode.
 template <int LOG2N1, bool OUTPUT = false>
-__global__ __launch_bounds__(THREADS, 4) void k_long_inv_cols(const float2 *__restrict__ Z, LongTw tw, LongPartial *__restrict__ part, int8_t *__restrict__ out = nullptr)
+__global__ __launch_bounds__(THREADS, 4) void k_long_inv_cols(const float2 *__restrict__ Z, LongTw tw, LongPartial *__restrict__ part, int8_t *__restrict__ out,
+                                                           int nwork)
 {
+    // persistent, like k_long_fwd_cols: work item w = (row w / ntiles, tile w % ntiles); the next item's 64 KiB of Z and its
+    // twiddle-table entries are in flight during the column transforms and the reduction of the current one
     constexpr int N1 = 1 << LOG2N1, LOG2C = LOG2TILE - LOG2N1, C = 1 << LOG2C;
+    constexpr int LOG2NT = LOG2N2 + LOG2N1 - LOG2TILE, NT = 1 << LOG2NT;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float2 *T = reinterpret_cast<float2 *>(smem);
     LongPartial *wred = reinterpret_cast<LongPartial *>(smem + sizeof(float2) * TILE);
-    const int tid = threadIdx.x, tile = blockIdx.x;
+    const int tid0 = threadIdx.x;
     const size_t B = (size_t)N1 * N2;
-    const float2 *Zr = Z + (size_t)blockIdx.y * B;
-    {
-        // a thread's 16 inputs as 8 column pairs: every load (8 x 16 bytes of Z, the twiddle-table entries) is in
-        // flight before the first product -- in a rolled loop each few elements cost a memory round trip
-        constexpr int PAIRS = TILE / 2 / THREADS;
-        constexpr bool LADDER = LOG2N1 >= 3;
-        float4 z[PAIRS];
-        float2 wa[LADDER ? 8 : 2 * PAIRS], wb[LADDER ? 8 : 2 * PAIRS];
+    // a thread's 16 inputs as 8 column pairs: every load (8 x 16 bytes of Z, the twiddle-table entries) is in
+    // flight before the first product -- in a rolled loop each few elements cost a memory round trip
+    constexpr int PAIRS = TILE / 2 / THREADS;
+    constexpr bool LADDER = LOG2N1 >= 3;
+    constexpr int LOG2S = LADDER ? LOG2N1 - 3 : 0;
+    float4 z[PAIRS];
+    Ladder la, lb_;
+    float2 ta[LADDER ? 1 : 2 * PAIRS], tb[LADDER ? 1 : 2 * PAIRS];
+    auto tile_of = [&](int w) { const int t = w & (NT - 1); return LB_DBG(2) ? ((t & 7) * (NT / 8) + (t >> 3)) : t; };
+    auto issue_z = [&](int w, int tid) {
+        const int tile = tile_of(w);
+        const float2 *Zr = Z + (size_t)(w >> LOG2NT) * B;
 #pragma unroll
         for (int i = 0; i < PAIRS; ++i) {
             const int e = 2 * (tid + i * THREADS), k1 = e >> LOG2C, c = e & (C - 1), n2 = tile * C + c;
             z[i] = *reinterpret_cast<const float4 *>(Zr + (size_t)k1 * N2 + n2);
         }
+    };
+    auto issue_tw = [&](int w, int tid) {
+        const int tile = tile_of(w);
         if constexpr (LADDER) {
-            constexpr int LOG2S = LOG2N1 - 3;
             const uint32_t k0 = (uint32_t)(2 * tid) >> LOG2C, n2 = (uint32_t)(tile * C + ((2 * tid) & (C - 1)));
-            Ladder la, lb_;
             ladder_issue(la, tw, n2, k0, 1u << LOG2S, 2u << LOG2S, 4u << LOG2S);
             ladder_issue(lb_, tw, n2 + 1u, k0, 1u << LOG2S, 2u << LOG2S, 4u << LOG2S);
-            ladder_expand(la, wa);
-            ladder_expand(lb_, wb);
         } else {
 #pragma unroll
             for (int i = 0; i < PAIRS; ++i) {
                 const int e = 2 * (tid + i * THREADS);
                 const uint32_t k1 = (uint32_t)(e >> LOG2C), n2 = (uint32_t)(tile * C + (e & (C - 1)));
                 const uint32_t m0 = (n2 * k1) & tw.bmask, m1 = ((n2 + 1u) * k1) & tw.bmask;
-                wa[2 * i] = tw.wc[m0 >> FBITS]; wb[2 * i] = tw.wf[m0 & FMASK];
-                wa[2 * i + 1] = tw.wc[m1 >> FBITS]; wb[2 * i + 1] = tw.wf[m1 & FMASK];
+                ta[2 * i] = tw.wc[m0 >> FBITS]; tb[2 * i] = tw.wf[m0 & FMASK];
+                ta[2 * i + 1] = tw.wc[m1 >> FBITS]; tb[2 * i + 1] = tw.wf[m1 & FMASK];
             }
         }
-#pragma unroll
-        for (int i = 0; i < PAIRS; ++i) {
-            const int e = 2 * (tid + i * THREADS);
-            float2 y0, y1;
+    };
+    int w = blockIdx.x;
+    if (w >= nwork) return;
+    issue_z(w, tid0);
+    issue_tw(w, tid0);
+    for (;;) {
+        int tid = tid0;                                 // opaque per iteration (see k_long_fwd_cols)
+        asm volatile("" : "+v"(tid));
+        const int tile = tile_of(w), rowi = w >> LOG2NT;
+        {
+            float2 wa[8], wb[8];
             if constexpr (LADDER) {
-                y0 = cmulc(make_float2(z[i].x, z[i].y), wa[i]);
-                y1 = cmulc(make_float2(z[i].z, z[i].w), wb[i]);
-            } else {
-                y0 = cmulc(make_float2(z[i].x, z[i].y), cmul(wa[2 * i], wb[2 * i]));
-                y1 = cmulc(make_float2(z[i].z, z[i].w), cmul(wa[2 * i + 1], wb[2 * i + 1]));
+                ladder_expand(la, wa);
+                ladder_expand(lb_, wb);
             }
-            *reinterpret_cast<float4 *>(T + e) = make_float4(y0.x, y0.y, y1.x, y1.y);
-        }
-    }
-    __syncthreads();
-    col_fft<LOG2N1, +1>(T, tw.tw1, tid);
-    if constexpr (OUTPUT) {
-        int8_t *orow = out + (size_t)blockIdx.y * B;
-        for (int e = 2 * tid; e < TILE; e += 2 * THREADS) {          // column pairs: one 32-bit store = samples n, n + 1
-            const int j = e >> LOG2C, c = e & (C - 1), n1 = rev_n1<LOG2N1>(j);
-            if (n1 >= N1 / 2) continue;
-            const float4 y = *reinterpret_cast<const float4 *>(T + e);
-            const uint32_t w = (uint32_t)(uint8_t)f32_to_i8(y.x) | ((uint32_t)(uint8_t)f32_to_i8(y.y) << 8) |
-                               ((uint32_t)(uint8_t)f32_to_i8(y.z) << 16) | ((uint32_t)(uint8_t)f32_to_i8(y.w) << 24);
-            *reinterpret_cast<uint32_t *>(orow + 2 * ((size_t)n1 * N2 + (size_t)(tile * C + c))) = w;
-        }
-        return;
-    }
-    float bm = -1.0f;
-    int bi = 0x7fffffff;
-    for (int e = tid; e < TILE; e += THREADS) {
-        const int j = e >> LOG2C, c = e & (C - 1);
-        const int n = rev_n1<LOG2N1>(j) * N2 + tile * C + c; // natural sample index of this output
-        const float2 y = T[e];
-        const float m = fmaf(y.x, y.x, y.y * y.y);
-        if (m > bm || (m == bm && n < bi)) { bm = m; bi = n; }
-    }
 #pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) {
-        const float om = __shfl_xor(bm, off, 64);
-        const int oi = __shfl_xor(bi, off, 64);
-        if (om > bm || (om == bm && oi < bi)) { bm = om; bi = oi; }
-    }
-    if ((tid & 63) == 0) wred[tid >> 6] = LongPartial{bm, bi};
-    __syncthreads();
-    if (tid == 0) {
-        LongPartial b = wred[0];
-        for (int w = 1; w < THREADS / 64; ++w)
-            if (wred[w].m > b.m || (wred[w].m == b.m && wred[w].idx < b.idx)) b = wred[w];
-        part[(size_t)blockIdx.y * gridDim.x + tile] = b;
+            for (int i = 0; i < PAIRS; ++i) {
+                const int e = 2 * (tid + i * THREADS);
+                float2 y0, y1;
+                if constexpr (LADDER) {
+                    y0 = cmulc(make_float2(z[i].x, z[i].y), wa[i]);
+                    y1 = cmulc(make_float2(z[i].z, z[i].w), wb[i]);
+                } else {
+                    y0 = cmulc(make_float2(z[i].x, z[i].y), cmul(ta[2 * i], tb[2 * i]));
+                    y1 = cmulc(make_float2(z[i].z, z[i].w), cmul(ta[2 * i + 1], tb[2 * i + 1]));
+                }
+                *reinterpret_cast<float4 *>(T + e) = make_float4(y0.x, y0.y, y1.x, y1.y);
+            }
+        }
+        __syncthreads();
+        const int wn = w + (int)gridDim.x;
+        if (wn < nwork) issue_z(wn, tid);                                    // 64 KiB in flight during the column transforms
+        if (!LB_DBG(1)) col_fft<LOG2N1, +1>(T, tw.tw1, tid);
+        if (wn < nwork) issue_tw(wn, tid);                                   // table entries (cache hits): under the reduction below
+        if constexpr (OUTPUT) {
+            int8_t *orow = out + (size_t)rowi * B;
+            for (int e = 2 * tid; e < TILE; e += 2 * THREADS) {          // column pairs: one 32-bit store = samples n, n + 1
+                const int j = e >> LOG2C, c = e & (C - 1), n1 = rev_n1<LOG2N1>(j);
+                if (n1 >= N1 / 2) continue;
+                const float4 y = *reinterpret_cast<const float4 *>(T + e);
+                const uint32_t wd = (uint32_t)(uint8_t)f32_to_i8(y.x) | ((uint32_t)(uint8_t)f32_to_i8(y.y) << 8) |
+                                    ((uint32_t)(uint8_t)f32_to_i8(y.z) << 16) | ((uint32_t)(uint8_t)f32_to_i8(y.w) << 24);
+                *reinterpret_cast<uint32_t *>(orow + 2 * ((size_t)n1 * N2 + (size_t)(tile * C + c))) = wd;
+            }
+        } else {
+            float bm = -1.0f;
+            int bi = 0x7fffffff;
+            for (int e = tid; e < (LB_DBG(1) ? 2 * THREADS : TILE); e += THREADS) {
+                const int j = e >> LOG2C, c = e & (C - 1);
+                const int n = rev_n1<LOG2N1>(j) * N2 + tile * C + c; // natural sample index of this output
+                const float2 y = T[e];
+                const float m = fmaf(y.x, y.x, y.y * y.y);
+                if (m > bm || (m == bm && n < bi)) { bm = m; bi = n; }
+            }
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) {
+                const float om = __shfl_xor(bm, off, 64);
+                const int oi = __shfl_xor(bi, off, 64);
+                if (om > bm || (om == bm && oi < bi)) { bm = om; bi = oi; }
+            }
+            if ((tid & 63) == 0) wred[tid >> 6] = LongPartial{bm, bi};
+            __syncthreads();
+            if (tid == 0) {
+                LongPartial b = wred[0];
+                for (int x = 1; x < THREADS / 64; ++x)
+                    if (wred[x].m > b.m || (wred[x].m == b.m && wred[x].idx < b.idx)) b = wred[x];
+                part[(size_t)rowi * NT + tile] = b;                       // [row][tile]
+            }
+        }
+        if (wn >= nwork) break;
+        w = wn;
+        __syncthreads();                                // the tile and the reduction scratch are free again
     }
 }
 
