@@ -357,22 +357,54 @@ __global__ __launch_bounds__(2 * QG, 1) void k_xcorr_lag14q(XcorrArgs a, const f
 // pass, last pass and stores are the OUTER section of a group and run beside the other group's image-owning middle section,
 // exactly as the int8 loads and the epilogue do in k_xcorr_lag14q.  cf32 in and out, in place; forward, x conj(ref), inverse.
 // items = lines: item i is line i of Y (row i / n1, frequency k1 = i % n1 -> its slice of the reference spectrum).
-__device__ __forceinline__ void q_line_p0_compute(c2 *v, const c2 *__restrict__ line, const c2 *__restrict__ twA, int vt)
+__device__ __forceinline__ void q_line_p0_transform(c2 *v, const c2 *__restrict__ twA, int vt)
 {
-#pragma unroll
-    for (int i = 0; i < 32; ++i) v[i] = line[i * 512 + vt];
     dft32<-1>(v);
     c2 w[32];
     tw_load(w, twA, TWA_STRIDE, vt);
     tw_apply<-1, true, 1>(v, w);
 }
-__device__ __forceinline__ void q_line_p0i_store(c2 *__restrict__ line, c2 *v, const c2 *__restrict__ twA, int vt)
+// the column pair (2m, 2m + 1) of a line / of the image as 16 bytes per lane
+__device__ __forceinline__ void q_line_load2(c2 *v, c2 *v2, const c2 *__restrict__ line, int m)
+{
+    const float4 *l4 = reinterpret_cast<const float4 *>(line);
+#pragma unroll
+    for (int i = 0; i < 32; ++i) {
+        const float4 x = l4[i * 256 + m];
+        v[i] = mk(x.x, x.y);
+        v2[i] = mk(x.z, x.w);
+    }
+}
+__device__ __forceinline__ void q_p0_store2(c2 *A, const c2 *v, const c2 *v2, int m)
+{
+    int base = p0_base(2 * m);            // even: the pair is 16-byte aligned in the image
+    asm volatile("" : "+v"(base));
+#pragma unroll
+    for (int k = 0; k < 32; ++k)
+        *reinterpret_cast<float4 *>(A + base + k * 528) = make_float4(v[xpos(k)].x, v[xpos(k)].y, v2[xpos(k)].x, v2[xpos(k)].y);
+}
+__device__ __forceinline__ void q_p0i_load2(c2 *v, c2 *v2, const c2 *A, int m)
+{
+    int base = p0_base(2 * m);
+    asm volatile("" : "+v"(base));
+#pragma unroll
+    for (int k = 0; k < 32; ++k) {
+        const float4 x = *reinterpret_cast<const float4 *>(A + base + k * 528);
+        v[k] = mk(x.x, x.y);
+        v2[k] = mk(x.z, x.w);
+    }
+}
+__device__ __forceinline__ void q_line_p0i_transform(c2 *v, const c2 *__restrict__ twA, int vt)
 {
     c2 w[32];
     tw_load(w, twA, TWA_STRIDE, vt);
     tw_dft32_inv(v, w);
+}
+__device__ __forceinline__ void q_line_store2(c2 *__restrict__ line, const c2 *v, const c2 *v2, int m)
+{
+    float4 *l4 = reinterpret_cast<float4 *>(line);
 #pragma unroll
-    for (int i = 0; i < 32; ++i) line[i * 512 + vt] = v[xpos(i)];      // natural order, coalesced
+    for (int i = 0; i < 32; ++i) l4[i * 256 + m] = make_float4(v[xpos(i)].x, v[xpos(i)].y, v2[xpos(i)].x, v2[xpos(i)].y);      // natural order, coalesced
 }
 
 __global__ __launch_bounds__(2 * QG, 1) void k_rows14_cf32q(c2 *__restrict__ Y, const c2 *__restrict__ twA, const c2 *__restrict__ twB,
@@ -398,15 +430,22 @@ __global__ __launch_bounds__(2 * QG, 1) void k_rows14_cf32q(c2 *__restrict__ Y, 
         c2 wB[32];
         {
             c2 v[32], v2[32];
-            q_line_p0_compute(v, line, twA, vt0);
-            __builtin_amdgcn_sched_barrier(0);           // keep the second half's 64 load registers out of the first half's transform
-            q_line_p0_compute(v2, line, twA, vt1);
+            // the outer passes work on the column PAIR (2 tid, 2 tid + 1) instead of (tid, tid + 256): neighbours in the line and
+            // in the image (p0_base(2m + 1) = p0_base(2m) + 1), so a pair travels as 16 bytes per lane -- global loads / stores
+            // and the image stores / loads of P0 / P0' are half as many instructions, twice as wide.  The image itself does not
+            // change, so the middle section keeps its columns (tid, tid + 256).  (Time per launch unchanged, 94.2 against 94.7 us,
+            // as it was with both halves' loads issued up front, 97.0: this stage is not waiting for its memory instructions.)
+            const int pc0 = 2 * vt0, pc1 = 2 * vt0 + 1;
+            q_line_load2(v, v2, line, vt0);
+            __builtin_amdgcn_sched_barrier(0);
+            q_line_p0_transform(v, twA, pc0);
+            __builtin_amdgcn_sched_barrier(0);
+            q_line_p0_transform(v2, twA, pc1);
             __builtin_amdgcn_sched_barrier(0);
             tw_load(wB, twB, TWB_STRIDE, tid & 15);
             q_acquire(sy, 2 * k + g + 1);
             __builtin_amdgcn_s_setprio(Q_PRIO);
-            q_p0_store(A, v, vt0);
-            q_p0_store(A, v2, vt1);
+            q_p0_store2(A, v, v2, vt0);
         }
         float4 ra[8], rb[8];
         q_refspec_load(ra, refspec4, vt0, 0);
@@ -428,15 +467,16 @@ __global__ __launch_bounds__(2 * QG, 1) void k_rows14_cf32q(c2 *__restrict__ Y, 
         if (tid == 0) sy->next[g] = 2 * (int)gridDim.x + (int)(atomicAdd(work, 1u) - work_base);
         {
             c2 v[32], v2[32];
-            q_p0i_load(v, A, vt0);
-            q_p0i_load(v2, A, vt1);
+            q_p0i_load2(v, v2, A, vt0);
             q_release(sy);                               // the line is in registers: the image goes to the other group
             __builtin_amdgcn_s_setprio(0);
-            int vs0 = tid, vs1 = tid + QG;               // opaque again: 64 load addresses kept for the stores would be 128 registers
-            asm volatile("" : "+v"(vs0), "+v"(vs1));
-            q_line_p0i_store(line, v, twA, vs0);
+            int vs0 = tid;                               // opaque again: store addresses kept from the loads would be 64 registers
+            asm volatile("" : "+v"(vs0));
+            q_line_p0i_transform(v, twA, 2 * vs0);
             __builtin_amdgcn_sched_barrier(0);
-            q_line_p0i_store(line, v2, twA, vs1);
+            q_line_p0i_transform(v2, twA, 2 * vs0 + 1);
+            __builtin_amdgcn_sched_barrier(0);
+            q_line_store2(line, v, v2, vs0);
         }
         q_barrier(sy, g, gen, 2);                        // next[g] (written after barrier 1) is visible to the whole group
         item = sy->next[g];
