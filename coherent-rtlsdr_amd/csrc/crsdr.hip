@@ -366,11 +366,13 @@ static hipError_t launch_long_rows_q(hipStream_t s, int n1, int nrows_launch, fl
     if (e != hipSuccess) return e;
     const int items = n1 * nrows_launch;
     static const int qspin = [] { const char *ev = getenv("CRSDR_K1_QSPIN"); return ev ? atoi(ev) : x14p::kQSpinLimit; }();
-    hipLaunchKernelGGL(kq, dim3((unsigned)std::max(1, std::min(cus, (items + 1) / 2))), dim3(2 * x14p::QG), x14p::LDSQ_BYTES, s, reinterpret_cast<c2 *>(Y),
-                       reinterpret_cast<const c2 *>(twA), reinterpret_cast<const c2 *>(twB), (const float4 *)refspec, n1, items, waitflag, work, *work_base, qspin);
-    e = hipGetLastError();
-    if (e == hipSuccess) *work_base += (unsigned)items;
-    return e;
+    static const int xcdq = [] { const char *ev = getenv("CRSDR_LONG_XCDQ"); return ev ? atoi(ev) : 1; }();      // 0: one queue, lines in memory order
+    const int grid = std::max(1, std::min(cus, (items + 1) / 2));
+    const int nq = (xcdq && n1 % 8 == 0 && grid % 8 == 0) ? 8 : 1;       // one queue per XCD (k_rows14_cf32q); static order: the work counter is not used
+    (void)work; (void)work_base;
+    hipLaunchKernelGGL(kq, dim3((unsigned)grid), dim3(2 * x14p::QG), x14p::LDSQ_BYTES, s, reinterpret_cast<c2 *>(Y),
+                       reinterpret_cast<const c2 *>(twA), reinterpret_cast<const c2 *>(twB), (const float4 *)refspec, n1, nrows_launch, nq, waitflag, qspin);
+    return hipGetLastError();
 }
 // stage B: the 16384-point row transforms run on the 32x32x16 structure of xcorr14.hpp
 template <bool IS_REF>

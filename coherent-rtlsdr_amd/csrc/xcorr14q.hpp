@@ -407,9 +407,15 @@ __device__ __forceinline__ void q_line_store2(c2 *__restrict__ line, const c2 *v
     for (int i = 0; i < 32; ++i) l4[i * 256 + m] = make_float4(v[xpos(i)].x, v[xpos(i)].y, v2[xpos(i)].x, v2[xpos(i)].y);      // natural order, coalesced
 }
 
+// Work order (static): line (row, k1) needs the k1-th 128 KiB slice of the reference spectrum, 16 MiB in all -- more than an XCD's
+// L2 holds, so with lines dealt out in memory order every line fetched its slice from the memory-side cache: a third of the
+// stage's traffic (measured with every line reading slice 0: 94 -> 83 us per launch).  Hence one queue per XCD: workgroup b runs
+// on XCD b % 8 (round-robin dispatch) and takes lines with k1 % 8 == b % 8, k1-major, so that the rows of one k1 pass through
+// one L2 at about the same time and its slice is fetched once per launch and XCD.  (The mapping only matters for speed: whatever
+// XCD a workgroup really runs on, every line is done exactly once.)  nq = 8 when n1 and the grid are multiples of 8, else 1.
 __global__ __launch_bounds__(2 * QG, 1) void k_rows14_cf32q(c2 *__restrict__ Y, const c2 *__restrict__ twA, const c2 *__restrict__ twB,
-                                                           const float4 *__restrict__ refspec_base, int n1, int nitems, int *__restrict__ errflag,
-                                                           unsigned int *__restrict__ work, unsigned int work_base, int spin_limit)
+                                                           const float4 *__restrict__ refspec_base, int n1, int rows, int nq, int *__restrict__ errflag,
+                                                           int spin_limit)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     c2 *A = reinterpret_cast<c2 *>(smem);
@@ -419,14 +425,21 @@ __global__ __launch_bounds__(2 * QG, 1) void k_rows14_cf32q(c2 *__restrict__ Y, 
     if (threadIdx.x == 0) { sy->owner = 0; sy->relcnt = 0; sy->bar[0] = 0; sy->bar[1] = 0; sy->err = 0; sy->next[0] = 0; sy->next[1] = 0; sy->spin_limit = spin_limit; }
     __syncthreads();
     int gen = 0;
-    int item = g * (int)gridDim.x + (int)blockIdx.x;     // then from the global counter, as in k_xcorr_lag14q
+    const int q = (int)blockIdx.x % nq, nlocal = 2 * ((int)gridDim.x / nq);           // this workgroup's queue; groups working on it
+    const int lg = g * ((int)gridDim.x / nq) + (int)blockIdx.x / nq;                  // this group's place among them
+    const int nqueue = (n1 / nq) * rows;                                              // lines in the queue, k1-major
     for (int k = 0;; ++k) {
         int vt0 = tid, vt1 = tid + QG;
         asm volatile("" : "+v"(vt0), "+v"(vt1));
-        if ((unsigned)item >= (unsigned)nitems) break;
-        const int item_u = __builtin_amdgcn_readfirstlane(item);          // one item per group: scalar base addresses
+        const int j = lg + k * nlocal;
+        if (j >= nqueue) break;
+        const int item_u = __builtin_amdgcn_readfirstlane((j % rows) * n1 + (j / rows) * nq + q);      // line index in Y: row * n1 + k1 (scalar base addresses)
         c2 *line = Y + (size_t)item_u * N;
+#ifdef CRSDR_B_SPEC0      // diagnostic: every line reads spectrum slice 0 (wrong results; what the slices' traffic costs)
+        const float4 *__restrict__ refspec4 = refspec_base;
+#else
         const float4 *__restrict__ refspec4 = refspec_base + (size_t)(item_u % n1) * (N / 2);
+#endif
         c2 wB[32];
         {
             c2 v[32], v2[32];
@@ -464,7 +477,6 @@ __global__ __launch_bounds__(2 * QG, 1) void k_rows14_cf32q(c2 *__restrict__ Y, 
         pass1_inverse(A, wB, vt0);
         pass1_inverse(A, wB, vt1);
         q_barrier(sy, g, gen, 1);
-        if (tid == 0) sy->next[g] = 2 * (int)gridDim.x + (int)(atomicAdd(work, 1u) - work_base);
         {
             c2 v[32], v2[32];
             q_p0i_load2(v, v2, A, vt0);
@@ -478,8 +490,6 @@ __global__ __launch_bounds__(2 * QG, 1) void k_rows14_cf32q(c2 *__restrict__ Y, 
             __builtin_amdgcn_sched_barrier(0);
             q_line_store2(line, v, v2, vs0);
         }
-        q_barrier(sy, g, gen, 2);                        // next[g] (written after barrier 1) is visible to the whole group
-        item = sy->next[g];
     }
     if (threadIdx.x == 0 && errflag) {
         if (__hip_atomic_load(&sy->err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) atomicAdd(errflag, 1);
