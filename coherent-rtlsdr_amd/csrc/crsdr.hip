@@ -1359,8 +1359,10 @@ extern "C" int crsdr_plan_submit_batch(crsdr_plan *p, const void *rows, int mem_
         if (pe) HIP_TRY(hipEventRecord(pe[0], S));
         p->chain_armed[0] = p->chain_armed[1] = 0;   // this path keeps its integer sums in d_corr
         if (chunks > 1) HIP_TRY(hipMemsetAsync(p->d_corr, 0, sizeof(long long) * 2 * n * T, S)); // atomically accumulated
-        if (vec16) hipLaunchKernelGGL(k_phase_dot<true>, dim3(p->row_count, nblocks, chunks), dim3(kAlignThreads), 0, S, aa);
-        else hipLaunchKernelGGL(k_phase_dot<false>, dim3(p->row_count, nblocks, chunks), dim3(kAlignThreads), 0, S, aa);
+        // long rows: 32 KiB per workgroup with all 16 loads of a thread in flight at once (cfg5: 34 -> 30 us per block by the plan's events)
+        if (vec16 && chunks >= 2) hipLaunchKernelGGL((k_phase_dot<true, 8>), dim3(p->row_count, nblocks, chunks / 2), dim3(kAlignThreads), 0, S, aa);
+        else if (vec16) hipLaunchKernelGGL((k_phase_dot<true, 4>), dim3(p->row_count, nblocks, chunks), dim3(kAlignThreads), 0, S, aa);
+        else hipLaunchKernelGGL((k_phase_dot<false, 4>), dim3(p->row_count, nblocks, chunks), dim3(kAlignThreads), 0, S, aa);
         HIP_TRY(hipGetLastError());
         if (pe) HIP_TRY(hipEventRecord(pe[1], S));
     }

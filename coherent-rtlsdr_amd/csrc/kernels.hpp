@@ -277,7 +277,9 @@ __device__ __forceinline__ void dot_word(uint32_t s, uint32_t r, int &re, int &i
     im -= __builtin_amdgcn_sdot4((int)sw, (int)(r & 0xFF00FF00u), 0, false);      // - I.rQ
 }
 
-template <bool VEC>
+// U: 16-byte vectors a thread has in flight per loop iteration (4: one 16 KiB chunk per pass of the workgroup; 8: the long
+// rows' 32 KiB chunks in one pass -- 16 loads out before the first use instead of two rounds of 8)
+template <bool VEC, int U = 4>
 __global__ __launch_bounds__(kAlignThreads) void k_phase_dot(AlignArgs a)
 {
     __shared__ long long sred[2 * (kAlignThreads / 64)];
@@ -296,16 +298,16 @@ __global__ __launch_bounds__(kAlignThreads) void k_phase_dot(AlignArgs a)
     if constexpr (VEC) {
         const int8_t *srow = blk + (size_t)row * B;
         const uint4 *r128 = reinterpret_cast<const uint4 *>(blk);
-        for (int i0 = v_lo + tid; i0 < v_hi; i0 += 4 * kAlignThreads) {
-            uint4 sv[4], rv[4];
+        for (int i0 = v_lo + tid; i0 < v_hi; i0 += U * kAlignThreads) {
+            uint4 sv[U], rv[U];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
+            for (int q = 0; q < U; ++q) {
                 const int i = i0 + q * kAlignThreads;
                 rv[q] = r128[i < v_hi ? i : i0];
             }
-            shifted_vecs<4>(sv, srow, i0, kAlignThreads, v_hi, d, L, a.xor80);
+            shifted_vecs<U>(sv, srow, i0, kAlignThreads, v_hi, d, L, a.xor80);
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
+            for (int q = 0; q < U; ++q) {
                 if (i0 + q * kAlignThreads < v_hi) {
                     dot_word(sv[q].x, rv[q].x ^ a.xor80, re, im);
                     dot_word(sv[q].y, rv[q].y ^ a.xor80, re, im);
