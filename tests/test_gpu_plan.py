@@ -617,15 +617,20 @@ def test_long_block_two_line_stage_b_is_bit_identical(tmp_path):
             plan.close()
         np.savez(sys.argv[1], **res)
     ''') % root
+    # Also equal, bit for bit: the other work orders of the stages -- stage B's lines in memory order instead of one queue per
+    # XCD (CRSDR_LONG_XCDQ=0), stage A with one workgroup per tile instead of persistent ones, stage C persistent.
     res = {}
-    for q in ("0", "1"):
+    variants = {"0": {"CRSDR_LONG_Q": "0"}, "1": {"CRSDR_LONG_Q": "1"},
+                "orders": {"CRSDR_LONG_Q": "1", "CRSDR_LONG_XCDQ": "0", "CRSDR_LONG_PERSIST": "0", "CRSDR_LONG_PERSIST_C": "2"}}
+    for q, env in variants.items():
         out = tmp_path / f"longq{q}.npz"
-        r = subprocess.run([sys.executable, "-c", code, str(out)], env=dict(os.environ, CRSDR_LONG_Q=q), capture_output=True, text=True, timeout=600)
+        r = subprocess.run([sys.executable, "-c", code, str(out)], env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stdout + r.stderr
         res[q] = np.load(out)
-    assert set(res["0"].files) == set(res["1"].files) and len(res["0"].files) == 12
+    assert set(res["0"].files) == set(res["1"].files) == set(res["orders"].files) and len(res["0"].files) == 12
     for key in res["0"].files:
         assert np.array_equal(res["0"][key].view(np.uint8), res["1"][key].view(np.uint8)), key
+        assert np.array_equal(res["0"][key].view(np.uint8), res["orders"][key].view(np.uint8)), ("orders", key)
 
 
 def test_two_row_kernel_reports_a_wait_that_ran_out(tmp_path):
