@@ -268,13 +268,22 @@ __device__ __forceinline__ void shifted_vecs(uint4 (&sv)[U], const int8_t *__res
     }
 }
 
-__device__ __forceinline__ void dot_word(uint32_t s, uint32_t r, int &re, int &im)
+// one word = two samples of s . conj(r): re += I.rI + Q.rQ, imp += Q.rI, imn += I.rQ (im = imp - imn once, at the end).
+// Six instructions per word: the byte swap is ONE v_perm_b32 (the shift / mask / or form compiled to three), and the
+// negative part has its own accumulator (accumulating "im -= dot" cost a zero and a subtraction per word): 10 -> 6.
+__device__ __forceinline__ void dot_word3(uint32_t s, uint32_t r, int &re, int &imp, int &imn)
 {
     // bytes of a word: [I0 Q0 I1 Q1]
-    const uint32_t sw = ((s >> 8) & 0x00FF00FFu) | ((s << 8) & 0xFF00FF00u);     // [Q0 I0 Q1 I1]
+    const uint32_t sw = __builtin_amdgcn_perm(s, s, 0x02030001u);                 // [Q0 I0 Q1 I1]
     re = __builtin_amdgcn_sdot4((int)s, (int)r, re, false);                       // I.rI + Q.rQ
-    im = __builtin_amdgcn_sdot4((int)sw, (int)(r & 0x00FF00FFu), im, false);      // + Q.rI
-    im -= __builtin_amdgcn_sdot4((int)sw, (int)(r & 0xFF00FF00u), 0, false);      // - I.rQ
+    imp = __builtin_amdgcn_sdot4((int)sw, (int)(r & 0x00FF00FFu), imp, false);    // Q.rI
+    imn = __builtin_amdgcn_sdot4((int)sw, (int)(r & 0xFF00FF00u), imn, false);    // I.rQ
+}
+__device__ __forceinline__ void dot_word(uint32_t s, uint32_t r, int &re, int &im)
+{
+    int imp = 0, imn = 0;
+    dot_word3(s, r, re, imp, imn);
+    im += imp - imn;
 }
 
 // U: 16-byte vectors a thread has in flight per loop iteration (4: one 16 KiB chunk per pass of the workgroup; 8: the long
@@ -291,7 +300,7 @@ __global__ __launch_bounds__(kAlignThreads) void k_phase_dot(AlignArgs a)
     const uint32_t *r32 = reinterpret_cast<const uint32_t *>(blk);
     const int d = align_shift(a, row, t);
     // int32 partials are safe (<= 2^16 per word, <= 2^13 words per thread)
-    int re = 0, im = 0;
+    int re = 0, im = 0, imp = 0, imn = 0;
     // long rows are split over grid.z chunks (one chunk for B <= 16 KiB)
     const int nchunk = gridDim.z, v_lo = (int)(((long long)(B / 16) * blockIdx.z) / nchunk),
               v_hi = (int)(((long long)(B / 16) * (blockIdx.z + 1)) / nchunk);
@@ -309,13 +318,14 @@ __global__ __launch_bounds__(kAlignThreads) void k_phase_dot(AlignArgs a)
 #pragma unroll
             for (int q = 0; q < U; ++q) {
                 if (i0 + q * kAlignThreads < v_hi) {
-                    dot_word(sv[q].x, rv[q].x ^ a.xor80, re, im);
-                    dot_word(sv[q].y, rv[q].y ^ a.xor80, re, im);
-                    dot_word(sv[q].z, rv[q].z ^ a.xor80, re, im);
-                    dot_word(sv[q].w, rv[q].w ^ a.xor80, re, im);
+                    dot_word3(sv[q].x, rv[q].x ^ a.xor80, re, imp, imn);
+                    dot_word3(sv[q].y, rv[q].y ^ a.xor80, re, imp, imn);
+                    dot_word3(sv[q].z, rv[q].z ^ a.xor80, re, imp, imn);
+                    dot_word3(sv[q].w, rv[q].w ^ a.xor80, re, imp, imn);
                 }
             }
         }
+        im = imp - imn;
     } else {
         for (int i = 4 * v_lo + tid; i < 4 * v_hi; i += kAlignThreads) {
             const uint32_t s = (d == 0) ? (s32[i] ^ a.xor80) : shifted_word(s32, i, d, L, a.xor80);
@@ -624,17 +634,18 @@ __global__ __launch_bounds__(kAlignThreads, 8) void k_align_fused(AlignArgs a_, 
 #pragma unroll
     for (int q = 0; q < 4; ++q) sv[q] = make_uint4(sv[q].x ^ a.xor80, sv[q].y ^ a.xor80, sv[q].z ^ a.xor80, sv[q].w ^ a.xor80);
     if (a.refnoise) {
-        int re = 0, im = 0;
+        int re = 0, imp = 0, imn = 0;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int i = tid + q * kAlignThreads;
             if (FULL || i < nvec) {
-                dot_word(sv[q].x, rv[q].x ^ a.xor80, re, im);
-                dot_word(sv[q].y, rv[q].y ^ a.xor80, re, im);
-                dot_word(sv[q].z, rv[q].z ^ a.xor80, re, im);
-                dot_word(sv[q].w, rv[q].w ^ a.xor80, re, im);
+                dot_word3(sv[q].x, rv[q].x ^ a.xor80, re, imp, imn);
+                dot_word3(sv[q].y, rv[q].y ^ a.xor80, re, imp, imn);
+                dot_word3(sv[q].z, rv[q].z ^ a.xor80, re, imp, imn);
+                dot_word3(sv[q].w, rv[q].w ^ a.xor80, re, imp, imn);
             }
         }
+        int im = imp - imn;
         // B <= 16384 here: |sum| <= 8192 * 2 * 127^2 < 2^28, so the wave sums are exact in 32 bits (six DPP adds each)
         re = wave_sum_lane63(re);
         im = wave_sum_lane63(im);
