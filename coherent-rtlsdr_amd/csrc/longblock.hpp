@@ -58,15 +58,23 @@ __device__ __forceinline__ int rev_n1(int j) { return digit_reverse<LOG2N1>(j); 
 // C = TILE / N1 independent N1-point DIF transforms along the rows of an LDS tile laid out
 // [n1][C] (same orientation as global memory, lanes run along the C columns: conflict-free).
 // Leaves X_col[rev(j)] in tile row j.  Caller syncs before; this syncs after every pass.
-template <int LOG2N1, int DIR, int P = 0>
-__device__ __forceinline__ void col_fft(float2 *T, const float2 *__restrict__ tw1, int tid)
+// Sink (optional): called as sink(v, R, base, stride, it) for every group of the LAST pass instead of storing it back (output i
+// of the group is tile element base + i * stride; it = which of the thread's groups, a constant after unrolling) -- a consumer
+// that only reduces or streams the outputs (stage C's |.|^2 / argmax, stage A's twiddle + store) takes them from the registers
+// and saves the tile's last write, its re-read and one barrier.
+struct NoSink {};
+template <int LOG2N1, int DIR, int P = 0, typename Sink = NoSink>
+__device__ __forceinline__ void col_fft(float2 *T, const float2 *__restrict__ tw1, int tid, Sink sink = Sink())
 {
     using G = FftGeom<LOG2N1>;
+    constexpr bool SUNK = !__is_same(Sink, NoSink) && P == G::NPASS - 1;
     if constexpr (P < G::NPASS) {
         constexpr int LOG2C = LOG2TILE - LOG2N1, C = 1 << LOG2C;
         constexpr int LR = G::log2r(P), R = 1 << LR, LM = G::log2m(P), M = 1 << LM;
         constexpr int NG = TILE / R;
-        for (int g = tid; g < NG; g += THREADS) {
+#pragma unroll(SUNK ? NG / THREADS : 1)
+        for (int it = 0; it < NG / THREADS; ++it) {
+            const int g = tid + it * THREADS;
             const int c = g & (C - 1), gi = g >> LOG2C;
             const int blk = gi >> LM, n2 = gi & (M - 1);
             const int base = (((blk << (LM + LR)) + n2) << LOG2C) + c;
@@ -99,11 +107,15 @@ __device__ __forceinline__ void col_fft(float2 *T, const float2 *__restrict__ tw
                     for (int k = 1; k < R; ++k) v[k] = ctw<DIR>(v[k], tw1[(n2 * k) << (4 * P)]);
                 }
             }
+            if constexpr (SUNK) {
+                sink(v, R, base, (1 << LM) << LOG2C, it);
+            } else {
 #pragma unroll
-            for (int i = 0; i < R; ++i) T[base + ((i << LM) << LOG2C)] = v[i];
+                for (int i = 0; i < R; ++i) T[base + ((i << LM) << LOG2C)] = v[i];
+            }
         }
-        __syncthreads();
-        col_fft<LOG2N1, DIR, P + 1>(T, tw1, tid);
+        if constexpr (!SUNK) __syncthreads();
+        col_fft<LOG2N1, DIR, P + 1, Sink>(T, tw1, tid, sink);
     }
 }
 
@@ -154,6 +166,10 @@ __global__ __launch_bounds__(THREADS, 4) void k_long_fwd_cols(const int8_t *__re
     constexpr int WORDS = H * C / 2 / THREADS;     // = TILE / 4 / THREADS input words per thread, all loaded before the first use
     constexpr bool LADDER = LOG2N1 >= 3;
     constexpr int LOG2S = LADDER ? LOG2N1 - 3 : 0;                   // a thread's tile rows: j0 + (i << LOG2S)
+    // STREAM (N1 = 128: radix 16 x 8): the outputs go from the last pass's registers through their twiddles straight to Y -- a
+    // thread then owns, per group, ONE column in 8 consecutive tile rows jb .. jb + 7 (k1 = rev(jb) + 16 i), 8-byte stores that
+    // a wave still lays down as 512 contiguous bytes per k1 -- instead of a last write of the tile, a barrier and a re-read
+    constexpr bool STREAM = LOG2N1 == 7;
     uint32_t u[WORDS];
     Ladder la, lb_;
     // the loads of one work item: its int8 words and the table entries of its output twiddles (used after the column transforms)
@@ -168,7 +184,13 @@ __global__ __launch_bounds__(THREADS, 4) void k_long_fwd_cols(const int8_t *__re
     };
     auto issue_ladder = [&](int w, int tid) {
         const int tile = w & (NT - 1);
-        if constexpr (LADDER) {
+        if constexpr (STREAM) {
+            // group q of the last pass: g = tid + q * THREADS, column g % C, tile rows 8 (g / C) + i
+            constexpr uint32_t r1 = (uint32_t)digit_reverse_c<LOG2N1>(1), r2 = (uint32_t)digit_reverse_c<LOG2N1>(2), r4 = (uint32_t)digit_reverse_c<LOG2N1>(4);
+            const uint32_t c0 = (uint32_t)(tid & (C - 1)), jb0 = (uint32_t)(tid >> LOG2C) << 3, jb1 = (uint32_t)((tid + THREADS) >> LOG2C) << 3;
+            ladder_issue(la, tw, (uint32_t)(tile * C) + c0, (uint32_t)rev_n1<LOG2N1>((int)jb0), r1, r2, r4);
+            ladder_issue(lb_, tw, (uint32_t)(tile * C) + c0, (uint32_t)rev_n1<LOG2N1>((int)jb1), r1, r2, r4);
+        } else if constexpr (LADDER) {
             const uint32_t j0 = (uint32_t)(2 * tid) >> LOG2C, n2 = (uint32_t)(tile * C + ((2 * tid) & (C - 1)));
             const uint32_t k0 = (uint32_t)rev_n1<LOG2N1>((int)j0);
             constexpr uint32_t ks0 = (uint32_t)digit_reverse_c<LOG2N1>(1 << LOG2S), ks1 = (uint32_t)digit_reverse_c<LOG2N1>(2 << LOG2S),
@@ -203,8 +225,24 @@ __global__ __launch_bounds__(THREADS, 4) void k_long_fwd_cols(const int8_t *__re
         __syncthreads();
         const int wn = w + (int)gridDim.x;
         if (wn < nwork) issue_words(wn, tid);                                // in flight during the column transforms
-        if (!LB_DBG(4)) col_fft<LOG2N1, -1>(T, tw.tw1, tid);
         float2 *Yr = Y + (size_t)(IS_REF ? 0 : (w >> LOG2NT)) * B;
+        if constexpr (STREAM) {
+            auto put = [&](const float2 *v, int r, int base, int stride, int it) {
+                float2 wv[8];
+                ladder_expand(it == 0 ? la : lb_, wv);
+                const int c = base & (C - 1), jb = base >> LOG2C;
+                float2 *dst = Yr + (size_t)rev_n1<LOG2N1>(jb) * N2 + (tile * C + c);      // k1 = rev(jb) + 16 i
+#pragma unroll
+                for (int i = 0; i < 8; ++i) dst[(size_t)i * (N2 << 4)] = cmul(v[i], wv[i]);
+            };
+            col_fft<LOG2N1, -1, 0, decltype(put)>(T, tw.tw1, tid, put);
+            if (wn < nwork) issue_ladder(wn, tid);
+            if (wn >= nwork) break;
+            w = wn;
+            __syncthreads();
+            continue;
+        }
+        if (!LB_DBG(4)) col_fft<LOG2N1, -1>(T, tw.tw1, tid);
         if constexpr (LADDER) {
             ladder_expand(la, wa);
             ladder_expand(lb_, wb);
@@ -280,7 +318,12 @@ __global__ __launch_bounds__(THREADS, 4) void k_long_inv_cols(const float2 *__re
         const float2 *Zr = Z + (size_t)(w >> LOG2NT) * B;
 #pragma unroll
         for (int i = 0; i < PAIRS; ++i) {
-            const int e = 2 * (tid + i * THREADS), k1 = e >> LOG2C, c = e & (C - 1), n2 = tile * C + c;
+            const int e = 2 * (tid + i * THREADS);
+            int k1 = e >> LOG2C, c = e & (C - 1), n2 = tile * C + c;
+            if (LB_DBG(8)) {          // diagnostic (with bit 0): the same bytes as 2C-column x N1/2-row pieces -- twice the segment length
+                k1 = (e >> (LOG2C + 1)) + (N1 / 2) * (tile & 1);
+                n2 = (tile >> 1) * 2 * C + (e & (2 * C - 1));
+            }
             z[i] = *reinterpret_cast<const float4 *>(Zr + (size_t)k1 * N2 + n2);
         }
     };
@@ -332,7 +375,25 @@ __global__ __launch_bounds__(THREADS, 4) void k_long_inv_cols(const float2 *__re
         __syncthreads();
         const int wn = w + (int)gridDim.x;
         if (wn < nwork) issue_z(wn, tid);                                    // 64 KiB in flight during the column transforms
-        if (!LB_DBG(1)) col_fft<LOG2N1, +1>(T, tw.tw1, tid);
+        float bm = -1.0f;
+        int bi = 0x7fffffff;
+        // (a radix-16 last pass, N1 = 16 or 256, keeps the tile round trip: 16 outputs plus their indices in flight spilled 24-31 registers)
+        constexpr bool FROM_REGS = !OUTPUT && FftGeom<LOG2N1>::log2r(FftGeom<LOG2N1>::NPASS - 1) <= 3;
+        if constexpr (!FROM_REGS) {
+            col_fft<LOG2N1, +1>(T, tw.tw1, tid);
+        } else {
+            // |.|^2 and the running (first) maximum straight from the last pass's registers
+            auto take = [&](const float2 *v, int r, int base, int stride, int) {
+#pragma unroll
+                for (int i = 0; i < r; ++i) {
+                    const int e = base + i * stride, j = e >> LOG2C, c = e & (C - 1);
+                    const int n = rev_n1<LOG2N1>(j) * N2 + tile * C + c; // natural sample index of this output
+                    const float m = fmaf(v[i].x, v[i].x, v[i].y * v[i].y);
+                    if (m > bm || (m == bm && n < bi)) { bm = m; bi = n; }
+                }
+            };
+            if (!LB_DBG(1)) col_fft<LOG2N1, +1, 0, decltype(take)>(T, tw.tw1, tid, take);
+        }
         if (wn < nwork) issue_tw(wn, tid);                                   // table entries (cache hits): under the reduction below
         if constexpr (OUTPUT) {
             int8_t *orow = out + (size_t)rowi * B;
@@ -345,14 +406,16 @@ __global__ __launch_bounds__(THREADS, 4) void k_long_inv_cols(const float2 *__re
                 *reinterpret_cast<uint32_t *>(orow + 2 * ((size_t)n1 * N2 + (size_t)(tile * C + c))) = wd;
             }
         } else {
-            float bm = -1.0f;
-            int bi = 0x7fffffff;
-            for (int e = tid; e < (LB_DBG(1) ? 2 * THREADS : TILE); e += THREADS) {
-                const int j = e >> LOG2C, c = e & (C - 1);
-                const int n = rev_n1<LOG2N1>(j) * N2 + tile * C + c; // natural sample index of this output
-                const float2 y = T[e];
-                const float m = fmaf(y.x, y.x, y.y * y.y);
-                if (m > bm || (m == bm && n < bi)) { bm = m; bi = n; }
+            if constexpr (!FROM_REGS) {
+                for (int e = tid; e < TILE; e += THREADS) {
+                    const int j = e >> LOG2C, c = e & (C - 1);
+                    const int n = rev_n1<LOG2N1>(j) * N2 + tile * C + c; // natural sample index of this output
+                    const float2 y = T[e];
+                    const float m = fmaf(y.x, y.x, y.y * y.y);
+                    if (m > bm || (m == bm && n < bi)) { bm = m; bi = n; }
+                }
+            } else if (LB_DBG(1)) {
+                for (int e = tid; e < 2 * THREADS; e += THREADS) { const float2 y = T[e]; const float m = fmaf(y.x, y.x, y.y * y.y); if (m > bm) { bm = m; bi = e; } }
             }
 #pragma unroll
             for (int off = 32; off >= 1; off >>= 1) {
