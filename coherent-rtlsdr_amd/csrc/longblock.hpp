@@ -62,12 +62,17 @@ __device__ __forceinline__ int rev_n1(int j) { return digit_reverse<LOG2N1>(j); 
 // of the group is tile element base + i * stride; it = which of the thread's groups, a constant after unrolling) -- a consumer
 // that only reduces or streams the outputs (stage C's |.|^2 / argmax, stage A's twiddle + store) takes them from the registers
 // and saves the tile's last write, its re-read and one barrier.
+// Source (optional): called as source(v, R, base, stride, it) to FILL the inputs of every group of the FIRST pass instead of
+// reading them from the tile (stage A at N1 = 128: int8 straight from global memory) -- saves the tile's first write, a
+// barrier and its first read.
 struct NoSink {};
-template <int LOG2N1, int DIR, int P = 0, typename Sink = NoSink>
-__device__ __forceinline__ void col_fft(float2 *T, const float2 *__restrict__ tw1, int tid, Sink sink = Sink())
+struct NoSource {};
+template <int LOG2N1, int DIR, int P = 0, typename Sink = NoSink, typename Source = NoSource>
+__device__ __forceinline__ void col_fft(float2 *T, const float2 *__restrict__ tw1, int tid, Sink sink = Sink(), Source source = Source())
 {
     using G = FftGeom<LOG2N1>;
     constexpr bool SUNK = !__is_same(Sink, NoSink) && P == G::NPASS - 1;
+    constexpr bool SOURCED = !__is_same(Source, NoSource) && P == 0;
     if constexpr (P < G::NPASS) {
         constexpr int LOG2C = LOG2TILE - LOG2N1, C = 1 << LOG2C;
         constexpr int LR = G::log2r(P), R = 1 << LR, LM = G::log2m(P), M = 1 << LM;
@@ -79,8 +84,12 @@ __device__ __forceinline__ void col_fft(float2 *T, const float2 *__restrict__ tw
             const int blk = gi >> LM, n2 = gi & (M - 1);
             const int base = (((blk << (LM + LR)) + n2) << LOG2C) + c;
             float2 v[R];
+            if constexpr (SOURCED) {
+                source(v, R, base, (1 << LM) << LOG2C, it);
+            } else {
 #pragma unroll
-            for (int i = 0; i < R; ++i) v[i] = T[base + ((i << LM) << LOG2C)];
+                for (int i = 0; i < R; ++i) v[i] = T[base + ((i << LM) << LOG2C)];
+            }
             dft<R, DIR>(v);
             if constexpr (M > 1) {
                 if constexpr (LOG2C >= 6) {
@@ -115,7 +124,7 @@ __device__ __forceinline__ void col_fft(float2 *T, const float2 *__restrict__ tw
             }
         }
         if constexpr (!SUNK) __syncthreads();
-        col_fft<LOG2N1, DIR, P + 1, Sink>(T, tw1, tid, sink);
+        col_fft<LOG2N1, DIR, P + 1, Sink, Source>(T, tw1, tid, sink, source);
     }
 }
 
@@ -171,11 +180,21 @@ __global__ __launch_bounds__(THREADS, 4) void k_long_fwd_cols(const int8_t *__re
     // a wave still lays down as 512 contiguous bytes per k1 -- instead of a last write of the tile, a barrier and a re-read
     constexpr bool STREAM = LOG2N1 == 7;
     uint32_t u[WORDS];
+    uint16_t h[8];       // STREAM: the first pass's own inputs -- one column, the 8 non-zero rows n2 + 8 i of its radix-16 group
     Ladder la, lb_;
     // the loads of one work item: its int8 words and the table entries of its output twiddles (used after the column transforms)
     auto issue_words = [&](int w, int tid) {
         const int tile = w & (NT - 1), row = IS_REF ? 0 : row_begin + (w >> LOG2NT);
         const uint32_t *src = reinterpret_cast<const uint32_t *>(rows + (size_t)row * B); // word = 2 samples
+        if constexpr (STREAM) {
+            // first pass (radix 16, stride 8 rows): group g = tid: column g % C, rows (g / C) + 8 i; storage rows 0 .. H - 1 hold
+            // the non-zero half (tile rows 0 .. H - 1 of a signal row, H .. N1 - 1 of the reference row)
+            const uint16_t *s16 = reinterpret_cast<const uint16_t *>(src);
+            const int c = tid & (C - 1), n2 = tid >> LOG2C;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) h[i] = s16[(size_t)(n2 + 8 * i) * N2 + (size_t)tile * C + c];
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < WORDS; ++i) {
             const int x = tid + i * THREADS, n1 = (2 * x) >> LOG2C, c = (2 * x) & (C - 1);
@@ -209,24 +228,36 @@ __global__ __launch_bounds__(THREADS, 4) void k_long_fwd_cols(const int8_t *__re
         int tid = tid0;
         asm volatile("" : "+v"(tid));
         const int tile = w & (NT - 1);
+        if constexpr (!STREAM) {
 #pragma unroll
-        for (int i = 0; i < WORDS; ++i) {
-            const int xw = tid + i * THREADS, n1 = (2 * xw) >> LOG2C, c = (2 * xw) & (C - 1);
-            const uint32_t x = u[i] ^ xor80;
-            const int r = IS_REF ? n1 + H : n1;
-            *reinterpret_cast<float4 *>(T + (r << LOG2C) + c) =
-                make_float4(i8_to_f32(sext8(x, 0)), i8_to_f32(sext8(x, 1)), i8_to_f32(sext8(x, 2)), i8_to_f32(sext8(x, 3)));
+            for (int i = 0; i < WORDS; ++i) {
+                const int xw = tid + i * THREADS, n1 = (2 * xw) >> LOG2C, c = (2 * xw) & (C - 1);
+                const uint32_t x = u[i] ^ xor80;
+                const int r = IS_REF ? n1 + H : n1;
+                *reinterpret_cast<float4 *>(T + (r << LOG2C) + c) =
+                    make_float4(i8_to_f32(sext8(x, 0)), i8_to_f32(sext8(x, 1)), i8_to_f32(sext8(x, 2)), i8_to_f32(sext8(x, 3)));
+            }
+            for (int e = tid; e < H * C; e += THREADS) T[((IS_REF ? 0 : H) << LOG2C) + e] = make_float2(0.f, 0.f);
         }
-        for (int e = tid; e < H * C; e += THREADS) T[((IS_REF ? 0 : H) << LOG2C) + e] = make_float2(0.f, 0.f);
         // a thread's 16 outputs as 8 column pairs, 16-byte stores; twiddles from the ladder (N1 >= 8) or, for the two
         // shortest sizes, 32 table entries all issued before the first product
         constexpr int PAIRS = TILE / 2 / THREADS;
         float2 wa[LADDER ? 8 : 2 * PAIRS], wb[LADDER ? 8 : 2 * PAIRS];
-        __syncthreads();
         const int wn = w + (int)gridDim.x;
-        if (wn < nwork) issue_words(wn, tid);                                // in flight during the column transforms
         float2 *Yr = Y + (size_t)(IS_REF ? 0 : (w >> LOG2NT)) * B;
         if constexpr (STREAM) {
+            // inputs of the first pass from the registers: 8 samples of one column, the other 8 rows of the group are the zero pad
+            uint32_t hx[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) hx[i] = (uint32_t)h[i] ^ (xor80 & 0xFFFFu);
+            if (wn < nwork) issue_words(wn, tid);                            // the next item's: in flight during the column transforms
+            auto get = [&](float2 *v, int r, int, int, int) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    v[IS_REF ? i + 8 : i] = make_float2(i8_to_f32(sext8(hx[i], 0)), i8_to_f32(sext8(hx[i], 1)));
+                    v[IS_REF ? i : i + 8] = make_float2(0.f, 0.f);
+                }
+            };
             auto put = [&](const float2 *v, int r, int base, int stride, int it) {
                 float2 wv[8];
                 ladder_expand(it == 0 ? la : lb_, wv);
@@ -235,13 +266,15 @@ __global__ __launch_bounds__(THREADS, 4) void k_long_fwd_cols(const int8_t *__re
 #pragma unroll
                 for (int i = 0; i < 8; ++i) dst[(size_t)i * (N2 << 4)] = cmul(v[i], wv[i]);
             };
-            col_fft<LOG2N1, -1, 0, decltype(put)>(T, tw.tw1, tid, put);
+            col_fft<LOG2N1, -1, 0, decltype(put), decltype(get)>(T, tw.tw1, tid, put, get);
             if (wn < nwork) issue_ladder(wn, tid);
             if (wn >= nwork) break;
             w = wn;
             __syncthreads();
             continue;
         }
+        __syncthreads();
+        if (wn < nwork) issue_words(wn, tid);                                // in flight during the column transforms
         if (!LB_DBG(4)) col_fft<LOG2N1, -1>(T, tw.tw1, tid);
         if constexpr (LADDER) {
             ladder_expand(la, wa);
