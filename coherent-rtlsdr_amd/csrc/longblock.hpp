@@ -154,6 +154,30 @@ __device__ __forceinline__ void ladder_expand(const Ladder &l, float2 *w)
     w[4] = cmul(b, s2); w[5] = cmul(w[1], s2); w[6] = cmul(w[2], s2); w[7] = cmul(w[3], s2);
 }
 
+// the same for 16 twiddles W_B^(n2 (k0 + sum_b bit_b(i) ks[b])), i < 16: five table products, four levels
+struct Ladder16 {
+    float2 g[10];
+};
+__device__ __forceinline__ void ladder16_issue(Ladder16 &l, const LongTw &t, uint32_t n2, uint32_t k0, uint32_t ks0, uint32_t ks1, uint32_t ks2, uint32_t ks3)
+{
+    const uint32_t m[5] = {(n2 * k0) & t.bmask, (n2 * ks0) & t.bmask, (n2 * ks1) & t.bmask, (n2 * ks2) & t.bmask, (n2 * ks3) & t.bmask};
+#pragma unroll
+    for (int q = 0; q < 5; ++q) {
+        l.g[2 * q] = t.wc[m[q] >> FBITS];
+        l.g[2 * q + 1] = t.wf[m[q] & FMASK];
+    }
+}
+__device__ __forceinline__ void ladder16_expand(const Ladder16 &l, float2 *w)
+{
+    w[0] = cmul(l.g[0], l.g[1]);
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+        const float2 sb = cmul(l.g[2 + 2 * b], l.g[3 + 2 * b]);
+#pragma unroll
+        for (int i = 0; i < (1 << b); ++i) w[i + (1 << b)] = cmul(w[i], sb);
+    }
+}
+
 // ---- A: int8 -> column FFTs -> x W_B^(n2 k1) -> Y[k1][n2] -------------------------------------------
 // Work item w = (row w / ntiles, tile w % ntiles); tile = columns [tile*C, (tile+1)*C), C = TILE / N1.  Signal rows carry
 // samples at n < L (n1 < N1/2), the ref row at n >= L (src/crtlsdr.cc:205-207,215-218).
@@ -342,13 +366,25 @@ __global__ __launch_bounds__(THREADS, 4) void k_long_inv_cols(const float2 *__re
     constexpr int PAIRS = TILE / 2 / THREADS;
     constexpr bool LADDER = LOG2N1 >= 3;
     constexpr int LOG2S = LADDER ? LOG2N1 - 3 : 0;
+    // STREAM (N1 = 128: radix 16 x 8): the first pass takes its inputs from global memory -- a thread's radix-16 group is one
+    // column in the tile rows r + 8 i: 16 loads of 8 bytes that a wave lays down as 512 contiguous bytes per k1 -- times their
+    // twiddles (a four-level ladder), instead of filling the tile first: one tile write, one barrier and one tile read less
+    constexpr bool STREAM = LOG2N1 == 7;
     float4 z[PAIRS];
+    float2 zz[STREAM ? 16 : 1];
     Ladder la, lb_;
+    Ladder16 l16;
     float2 ta[LADDER ? 1 : 2 * PAIRS], tb[LADDER ? 1 : 2 * PAIRS];
     auto tile_of = [&](int w) { const int t = w & (NT - 1); return LB_DBG(2) ? ((t & 7) * (NT / 8) + (t >> 3)) : t; };
     auto issue_z = [&](int w, int tid) {
         const int tile = tile_of(w);
         const float2 *Zr = Z + (size_t)(w >> LOG2NT) * B;
+        if constexpr (STREAM) {
+            const int c = tid & (C - 1), r = tid >> LOG2C;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) zz[i] = Zr[(size_t)(r + 8 * i) * N2 + tile * C + c];
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < PAIRS; ++i) {
             const int e = 2 * (tid + i * THREADS);
@@ -362,7 +398,9 @@ __global__ __launch_bounds__(THREADS, 4) void k_long_inv_cols(const float2 *__re
     };
     auto issue_tw = [&](int w, int tid) {
         const int tile = tile_of(w);
-        if constexpr (LADDER) {
+        if constexpr (STREAM) {
+            ladder16_issue(l16, tw, (uint32_t)(tile * C + (tid & (C - 1))), (uint32_t)(tid >> LOG2C), 8u, 16u, 32u, 64u);
+        } else if constexpr (LADDER) {
             const uint32_t k0 = (uint32_t)(2 * tid) >> LOG2C, n2 = (uint32_t)(tile * C + ((2 * tid) & (C - 1)));
             ladder_issue(la, tw, n2, k0, 1u << LOG2S, 2u << LOG2S, 4u << LOG2S);
             ladder_issue(lb_, tw, n2 + 1u, k0, 1u << LOG2S, 2u << LOG2S, 4u << LOG2S);
@@ -385,7 +423,7 @@ __global__ __launch_bounds__(THREADS, 4) void k_long_inv_cols(const float2 *__re
         int tid = tid0;                                 // opaque per iteration (see k_long_fwd_cols)
         asm volatile("" : "+v"(tid));
         const int tile = tile_of(w), rowi = w >> LOG2NT;
-        {
+        if constexpr (!STREAM) {
             float2 wa[8], wb[8];
             if constexpr (LADDER) {
                 ladder_expand(la, wa);
@@ -404,16 +442,27 @@ __global__ __launch_bounds__(THREADS, 4) void k_long_inv_cols(const float2 *__re
                 }
                 *reinterpret_cast<float4 *>(T + e) = make_float4(y0.x, y0.y, y1.x, y1.y);
             }
+            __syncthreads();
         }
-        __syncthreads();
         const int wn = w + (int)gridDim.x;
-        if (wn < nwork) issue_z(wn, tid);                                    // 64 KiB in flight during the column transforms
+        if constexpr (!STREAM) {
+            if (wn < nwork) issue_z(wn, tid);                                // 64 KiB in flight during the column transforms
+        }
+        // STREAM: the first pass's inputs = the loaded values times their twiddles; the next item's loads go out right behind
+        auto get = [&](float2 *v, int, int, int, int) {
+            float2 w16[16];
+            ladder16_expand(l16, w16);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) v[i] = cmulc(zz[STREAM ? i : 0], w16[i]);
+            if (wn < nwork) issue_z(wn, tid);
+        };
         float bm = -1.0f;
         int bi = 0x7fffffff;
         // (a radix-16 last pass, N1 = 16 or 256, keeps the tile round trip: 16 outputs plus their indices in flight spilled 24-31 registers)
         constexpr bool FROM_REGS = !OUTPUT && FftGeom<LOG2N1>::log2r(FftGeom<LOG2N1>::NPASS - 1) <= 3;
         if constexpr (!FROM_REGS) {
-            col_fft<LOG2N1, +1>(T, tw.tw1, tid);
+            if constexpr (STREAM) col_fft<LOG2N1, +1, 0, NoSink, decltype(get)>(T, tw.tw1, tid, NoSink(), get);
+            else col_fft<LOG2N1, +1>(T, tw.tw1, tid);
         } else {
             // |.|^2 and the running (first) maximum straight from the last pass's registers
             auto take = [&](const float2 *v, int r, int base, int stride, int) {
@@ -425,7 +474,8 @@ __global__ __launch_bounds__(THREADS, 4) void k_long_inv_cols(const float2 *__re
                     if (m > bm || (m == bm && n < bi)) { bm = m; bi = n; }
                 }
             };
-            if (!LB_DBG(1)) col_fft<LOG2N1, +1, 0, decltype(take)>(T, tw.tw1, tid, take);
+            if constexpr (STREAM) col_fft<LOG2N1, +1, 0, decltype(take), decltype(get)>(T, tw.tw1, tid, take, get);
+            else if (!LB_DBG(1)) col_fft<LOG2N1, +1, 0, decltype(take)>(T, tw.tw1, tid, take);
         }
         if (wn < nwork) issue_tw(wn, tid);                                   // table entries (cache hits): under the reduction below
         if constexpr (OUTPUT) {
