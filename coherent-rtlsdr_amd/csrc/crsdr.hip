@@ -862,7 +862,10 @@ static int plan_alloc(crsdr_plan *p)
         HIP_TRY(hipMalloc((void **)&p->d_Yref, sizeof(float2) * Bz));
         {
             const char *e = getenv("CRSDR_LONG_CHUNK_MB");
-            const long mb = e ? atol(e) : 200; // measured on cfg5 (21 x 2^21): 64 MB -4 %, 128 MB +1.5 %, 200 MB +4.7 %, unchunked 0
+            // r01, cfg5 (21 x 2^21, 352 MB): 64 MB -4 %, 128 MB +1.5 %, 200 MB +4.7 % against unchunked.  With the r02 column stages
+            // (register-first passes, persistent stage A) the launch boundaries weigh more than the cache residency of the work
+            // area: 64 MB 1 952, 100 MB 2 061, 136 MB 2 197, 170 MB 2 257, 200 MB 2 370, 240 MB 2 326, one chunk 2 460 blocks/s.
+            const long mb = e ? atol(e) : 400;
             if (mb > 0) p->long_chunk = (int)std::max<size_t>(1, ((size_t)mb << 20) / (sizeof(float2) * Bz));
         }
         HIP_TRY(hipMalloc((void **)&p->d_part, sizeof(lb::LongPartial) * (size_t)lb::ntiles(p->log2n1) * (size_t)p->row_count));
