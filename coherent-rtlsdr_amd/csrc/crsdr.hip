@@ -1205,6 +1205,7 @@ extern "C" int crsdr_plan_submit_batch(crsdr_plan *p, const void *rows, int mem_
     // stretches by exactly what the phase kernel costs alone (0.83 -> 0.96 ms per launch): extra waves take issue
     // slots from K1's two waves per SIMD rather than filling their stalls.  Off by default.
     const bool use_x = p->overlap && fused && any_lag && !p->longblock;
+    bool corr_zeroed = false;
     hipStream_t KS = use_x ? p->xs : S;
 
     if (any_lag && p->longblock) {
@@ -1258,7 +1259,8 @@ extern "C" int crsdr_plan_submit_batch(crsdr_plan *p, const void *rows, int mem_
         }
         HIP_TRY(hipEventRecord(p->ev_k1done[slot], S));       // the last reader of this block's reference spectrum has been enqueued
         p->k1done_valid[slot] = true;
-        hipLaunchKernelGGL(lb::k_long_finalize, dim3(p->row_count), dim3(256), 0, S, p->d_Y, p->d_part, tw, n1, lb::ntiles(l1), xa);
+        corr_zeroed = aa.refnoise && !fused && chunks > 1 && nblocks == 1;      // (the three-kernel path's integer sums: see below)
+        hipLaunchKernelGGL(lb::k_long_finalize, dim3(p->row_count), dim3(256), 0, S, p->d_Y, p->d_part, tw, n1, lb::ntiles(l1), xa, corr_zeroed ? p->d_corr : nullptr);
         HIP_TRY(hipGetLastError());
         if (pe1) HIP_TRY(hipEventRecord(pe1[1], S));
     } else if (any_lag) {
@@ -1361,7 +1363,7 @@ extern "C" int crsdr_plan_submit_batch(crsdr_plan *p, const void *rows, int mem_
         hipEvent_t *pe = prof_pair(p, CRSDR_KERNEL_PHASE_DOT);
         if (pe) HIP_TRY(hipEventRecord(pe[0], S));
         p->chain_armed[0] = p->chain_armed[1] = 0;   // this path keeps its integer sums in d_corr
-        if (chunks > 1) HIP_TRY(hipMemsetAsync(p->d_corr, 0, sizeof(long long) * 2 * n * T, S)); // atomically accumulated
+        if (chunks > 1 && !corr_zeroed) HIP_TRY(hipMemsetAsync(p->d_corr, 0, sizeof(long long) * 2 * n * T, S)); // atomically accumulated (k_long_finalize has zeroed a tracked block's)
         // long rows: 32 KiB per workgroup with all 16 loads of a thread in flight at once (cfg5: 34 -> 30 us per block by the plan's events)
         if (vec16 && chunks >= 2) hipLaunchKernelGGL((k_phase_dot<true, 8>), dim3(p->row_count, nblocks, chunks / 2), dim3(kAlignThreads), 0, S, aa);
         else if (vec16) hipLaunchKernelGGL((k_phase_dot<true, 4>), dim3(p->row_count, nblocks, chunks), dim3(kAlignThreads), 0, S, aa);

@@ -525,11 +525,14 @@ __global__ __launch_bounds__(THREADS, 4) void k_long_inv_cols(const float2 *__re
 // y[n] for a single n is an N1-term sum over the column of Z that holds it:
 //   y[n1 N2 + n2] = sum_k1 Z[k1][n2] conj(W_B^(n2 k1)) conj(W_N1^(n1 k1))
 __global__ __launch_bounds__(256) void k_long_finalize(const float2 *__restrict__ Z, const LongPartial *__restrict__ part, LongTw tw,
-                                                       int N1, int ntile, XcorrArgs a)
+                                                       int N1, int ntile, XcorrArgs a, long long *__restrict__ corr_zero)
 {
     __shared__ LongPartial sp[256];
     __shared__ float snb[2][2 * 256];
     const int tid = threadIdx.x, row = a.row_begin + (int)blockIdx.x, t = 0;
+    // the long rows' dot product accumulates its chunks into corr[row] with integer atomics: zeroed here, one kernel ahead of it,
+    // instead of by a memset of its own between the two (a launch and a gap per block)
+    if (corr_zero && tid < 2) corr_zero[2 * (size_t)row + tid] = 0;
     if (xcorr_skip(a, row, t, tid)) return;
     const size_t B = (size_t)N1 * N2;
     LongPartial b = {-1.0f, 0x7fffffff};
