@@ -1180,6 +1180,7 @@ extern "C" int crsdr_plan_submit_batch(crsdr_plan *p, const void *rows, int mem_
     aa.nrows = p->nrows; aa.B = p->B; aa.row_begin = p->row_begin; aa.nblocks = nblocks;
     aa.digital = (p->mode == CRSDR_MODE_DIGITAL); aa.refnoise = (flags & CRSDR_REFNOISE_ENABLED) ? 1 : 0;
     aa.xcorr_ran = any_lag ? 1 : 0;
+    aa.inline_chain = 0;
     // rows in and packet rows out are touched once: non-temporal (measured in the locked cadence, A/B in one call: stores +2.3 %, loads neutral)
     static const int k2_nt = [] { const char *e = getenv("CRSDR_K2_NT"); return e ? atoi(e) : 3; }();
     aa.nt = k2_nt;
@@ -1371,12 +1372,16 @@ extern "C" int crsdr_plan_submit_batch(crsdr_plan *p, const void *rows, int mem_
         HIP_TRY(hipGetLastError());
         if (pe) HIP_TRY(hipEventRecord(pe[1], S));
     }
-    hipLaunchKernelGGL(k_phase_chain, dim3((p->row_count + 63) / 64), dim3(64), 0, S, aa, p->row_count);
-    HIP_TRY(hipGetLastError());
+    const bool apply = p->frac_apply && p->longblock && aa.digital;
+    // long rows, one block per submit, rows rotated by k_align_quant itself: the single chain step is folded there
+    aa.inline_chain = (chunks > 1 && nblocks == 1 && !apply) ? 1 : 0;
+    if (!aa.inline_chain) {
+        hipLaunchKernelGGL(k_phase_chain, dim3((p->row_count + 63) / 64), dim3(64), 0, S, aa, p->row_count);
+        HIP_TRY(hipGetLastError());
+    }
     {
         hipEvent_t *pe = prof_pair(p, CRSDR_KERNEL_ALIGN_QUANT);
         if (pe) HIP_TRY(hipEventRecord(pe[0], S));
-        const bool apply = p->frac_apply && p->longblock && aa.digital;
         // with the fractional-delay correction on, the rows come from the apply pass below: here only header + readcnt + row 0
         const unsigned gx = apply ? 1u : 1u + (unsigned)p->row_count;
         if (vec16) hipLaunchKernelGGL(k_align_quant<true>, dim3(gx, nblocks, chunks), dim3(kAlignThreads), 0, S, aa);

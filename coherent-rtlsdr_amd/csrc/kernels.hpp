@@ -467,7 +467,28 @@ __global__ __launch_bounds__(kAlignThreads) void k_align_quant(AlignArgs a)
     const int d = align_shift(a, row, t);
     int8_t *orow = a.slab ? a.slab + (size_t)t * a.slab_stride + (size_t)(row - a.row_begin) * B : packet + moff + (size_t)row * B;
 
-    const float2 p = a.phasor[(size_t)t * a.nrows + row];      // get_phasecorrect() after block t (k_phase_chain)
+    float2 p;
+    if (a.inline_chain) {
+        // a one-block batch: the chain is a single step, folded here by every workgroup of the row (same operands, same
+        // operations as k_phase_chain: identical bits); chunk 0 publishes it -- one launch and one launch gap less per block
+        p = a.phase_in[row];
+        if (a.refnoise) {
+            const long long sr = a.corr[2 * ((size_t)t * a.nrows + row)], si = a.corr[2 * ((size_t)t * a.nrows + row) + 1];
+            if (sr != 0 || si != 0) {
+                const double cr = (double)sr, ci = (double)si;
+                const double inv = 1.0 / sqrt(cr * cr + ci * ci);
+                const float pr = (float)(cr * inv), pi = (float)(-ci * inv);
+                p = make_float2(__fadd_rn(__fmul_rn(0.5f, pr), __fmul_rn(0.5f, p.x)), __fadd_rn(__fmul_rn(0.5f, pi), __fmul_rn(0.5f, p.y)));
+            }
+        }
+        if (blockIdx.z == 0 && tid == 0) {
+            const size_t o = (size_t)t * a.nrows + row;
+            a.phasor[o] = p;
+            a.phase_out[row] = p;
+            if (!a.xcorr_ran) { a.lag_out[o] = a.lag_state[row]; a.mag_out[o] = a.mag_state[row]; a.frac_out[o] = a.frac_state[row]; }
+        }
+    } else
+        p = a.phasor[(size_t)t * a.nrows + row];      // get_phasecorrect() after block t (k_phase_chain)
 
     // csdrdevice::phasecorrect (src/csdrdevice.cc:80-84) + cpacketize::write(complex<float>*)
     // (src/cpacketizer.cc:158-172): y * p, x127, saturate, round-half-even, int8 at the row offset

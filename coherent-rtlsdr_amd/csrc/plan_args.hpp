@@ -62,6 +62,7 @@ struct AlignArgs {
     float2 *phasor;           // [T][nrows] get_phasecorrect() after each block
     int nrows, B, row_begin, nblocks;
     int digital, refnoise, xcorr_ran;
+    int inline_chain;         // one-block batches of long rows: k_align_quant folds the block's phasor itself (no k_phase_chain launch)
     int nt;                   // bit 0: non-temporal stores of the output rows, bit 1: non-temporal loads of the signal rows (both are touched once)
     uint32_t seq, xor80;
     // slab output (sharded plans, crsdr_plan_bind_slab): when slab != nullptr the owned rows of block t go to
