@@ -28,7 +28,7 @@ def _matrix_close(got, exp, frac_allowed):
     assert np.count_nonzero(d) <= frac_allowed * d.size, (np.count_nonzero(d), d.size)
 
 
-@pytest.mark.parametrize("log2B", [15, 16, 18])
+@pytest.mark.parametrize("log2B", [15, 16, 17, 18, 20])
 def test_frac_apply_matches_oracle_and_fp64_model(b, oracle, model, synth, log2B):
     nsig, B = 4, 1 << log2B
     L = B // 2
@@ -42,7 +42,9 @@ def test_frac_apply_matches_oracle_and_fp64_model(b, oracle, model, synth, log2B
         rows, _ = synth.make_block(nsig, L, seed, t, params=params)
         got, exp = plan.block(rows, seq=t), orc.block(rows, seq=t)
         assert np.array_equal(got["lag"], exp["lag"]) and np.array_equal(got["lag"][1:], params.d)
-        assert np.abs(np.angle(got["phasor"][1:] * np.conj(exp["phasor"][1:]))).max() <= 1e-5
+        # (the GPU's dot product is exact in integers; the fp32 oracle's sequential accumulator carries ~1e-5 rad of its own
+        # from 2^19 samples per row on: 1.1e-5 seen at B = 2^20)
+        assert np.abs(np.angle(got["phasor"][1:] * np.conj(exp["phasor"][1:]))).max() <= (1e-5 if log2B <= 18 else 3e-5)
         _matrix_close(got["matrix"], exp["matrix"], 2e-3)
         _matrix_close(got["matrix"], mod.block(rows)[4], 2e-3)
         assert np.array_equal(got["matrix"][0], rows[0])                       # raw reference row, header as ever

@@ -299,7 +299,7 @@ def test_batch_argument_checks(b):
 
 
 @pytest.mark.parametrize("mode", [0, 1])
-@pytest.mark.parametrize("log2B", [15, 16, 18])
+@pytest.mark.parametrize("log2B", [15, 16, 17, 18, 19, 20])      # N1 = 2 ... 64: every radix split of the column passes (128 and 256: the tests below)
 def test_long_block_plan_vs_oracle(b, oracle, model, synth, mode, log2B):
     # blocks longer than the LDS-resident 16384 points: B = N1 x 16384 four-step transform
     # (column FFTs -> row FFTs x conj(ref) -> inverse), chunked phase/rotate kernels
