@@ -199,24 +199,32 @@ __global__ __launch_bounds__(THREADS, 4) void k_long_fwd_cols(const int8_t *__re
     constexpr int WORDS = H * C / 2 / THREADS;     // = TILE / 4 / THREADS input words per thread, all loaded before the first use
     constexpr bool LADDER = LOG2N1 >= 3;
     constexpr int LOG2S = LADDER ? LOG2N1 - 3 : 0;                   // a thread's tile rows: j0 + (i << LOG2S)
-    // STREAM (N1 = 128: radix 16 x 8): the outputs go from the last pass's registers through their twiddles straight to Y -- a
-    // thread then owns, per group, ONE column in 8 consecutive tile rows jb .. jb + 7 (k1 = rev(jb) + 16 i), 8-byte stores that
-    // a wave still lays down as 512 contiguous bytes per k1 -- instead of a last write of the tile, a barrier and a re-read
-    constexpr bool STREAM = LOG2N1 == 7;
+    // STREAM (N1 >= 16: a radix-16 first pass with stride M0 = N1 / 16 rows, then radix RL = N1 / 16 -- or the one pass itself):
+    // the first pass reads its 8 non-zero int8 samples (one column, rows n2 + M0 i) straight from global memory, and the
+    // outputs go from the last pass's registers through their twiddles straight to Y: a thread then owns ONE column in 16 / RL
+    // runs of RL consecutive tile rows, 8-byte stores that a wave still lays down as contiguous runs per k1 -- no tile fill, no
+    // zero fill, no last write of the tile and re-read, two barriers less.  In k1 = rev(tile row) a thread's 16 outputs are
+    // k0 + (i << KSH) + rev(q * GSTEP) (i < RL its position in a run, q its run): one four-level twiddle ladder covers them.
+    using G = FftGeom<LOG2N1>;
+    constexpr bool STREAM = LOG2N1 >= 4;
+    constexpr int M0 = STREAM ? N1 / 16 : 1;
+    constexpr int LRL = G::log2r(G::NPASS - 1), RL = 1 << LRL, KSH = 4 * (G::NPASS - 1);
+    constexpr int GSTEP = ((THREADS >> LOG2C) << LRL);                // tile rows between a thread's consecutive runs
     uint32_t u[WORDS];
-    uint16_t h[8];       // STREAM: the first pass's own inputs -- one column, the 8 non-zero rows n2 + 8 i of its radix-16 group
+    uint16_t h[8];
     Ladder la, lb_;
+    Ladder16 l16;
     // the loads of one work item: its int8 words and the table entries of its output twiddles (used after the column transforms)
     auto issue_words = [&](int w, int tid) {
         const int tile = w & (NT - 1), row = IS_REF ? 0 : row_begin + (w >> LOG2NT);
         const uint32_t *src = reinterpret_cast<const uint32_t *>(rows + (size_t)row * B); // word = 2 samples
         if constexpr (STREAM) {
-            // first pass (radix 16, stride 8 rows): group g = tid: column g % C, rows (g / C) + 8 i; storage rows 0 .. H - 1 hold
+            // first pass (radix 16, stride M0 rows): group g = tid: column g % C, rows (g / C) + M0 i; storage rows 0 .. H - 1 hold
             // the non-zero half (tile rows 0 .. H - 1 of a signal row, H .. N1 - 1 of the reference row)
             const uint16_t *s16 = reinterpret_cast<const uint16_t *>(src);
             const int c = tid & (C - 1), n2 = tid >> LOG2C;
 #pragma unroll
-            for (int i = 0; i < 8; ++i) h[i] = s16[(size_t)(n2 + 8 * i) * N2 + (size_t)tile * C + c];
+            for (int i = 0; i < 8; ++i) h[i] = s16[(size_t)(n2 + M0 * i) * N2 + (size_t)tile * C + c];
             return;
         }
 #pragma unroll
@@ -228,11 +236,13 @@ __global__ __launch_bounds__(THREADS, 4) void k_long_fwd_cols(const int8_t *__re
     auto issue_ladder = [&](int w, int tid) {
         const int tile = w & (NT - 1);
         if constexpr (STREAM) {
-            // group q of the last pass: g = tid + q * THREADS, column g % C, tile rows 8 (g / C) + i
-            constexpr uint32_t r1 = (uint32_t)digit_reverse_c<LOG2N1>(1), r2 = (uint32_t)digit_reverse_c<LOG2N1>(2), r4 = (uint32_t)digit_reverse_c<LOG2N1>(4);
-            const uint32_t c0 = (uint32_t)(tid & (C - 1)), jb0 = (uint32_t)(tid >> LOG2C) << 3, jb1 = (uint32_t)((tid + THREADS) >> LOG2C) << 3;
-            ladder_issue(la, tw, (uint32_t)(tile * C) + c0, (uint32_t)rev_n1<LOG2N1>((int)jb0), r1, r2, r4);
-            ladder_issue(lb_, tw, (uint32_t)(tile * C) + c0, (uint32_t)rev_n1<LOG2N1>((int)jb1), r1, r2, r4);
+            // run q of the last pass: group tid + q * THREADS = column tid % C, tile rows ((tid / C) << LRL) + q * GSTEP + i, i < RL;
+            // ladder bit b < LRL is bit b of i, bit LRL + b' is bit b' of q
+            constexpr auto step = [](int b) -> uint32_t {
+                return b < LRL ? (uint32_t)((1 << b) << KSH) : (uint32_t)digit_reverse_c<LOG2N1>((GSTEP << (b - LRL)) & (N1 - 1));
+            };
+            const uint32_t c0 = (uint32_t)(tid & (C - 1)), jb0 = (uint32_t)(tid >> LOG2C) << LRL;
+            ladder16_issue(l16, tw, (uint32_t)(tile * C) + c0, (uint32_t)rev_n1<LOG2N1>((int)jb0), step(0), step(1), step(2), step(3));
         } else if constexpr (LADDER) {
             const uint32_t j0 = (uint32_t)(2 * tid) >> LOG2C, n2 = (uint32_t)(tile * C + ((2 * tid) & (C - 1)));
             const uint32_t k0 = (uint32_t)rev_n1<LOG2N1>((int)j0);
@@ -282,13 +292,13 @@ __global__ __launch_bounds__(THREADS, 4) void k_long_fwd_cols(const int8_t *__re
                     v[IS_REF ? i : i + 8] = make_float2(0.f, 0.f);
                 }
             };
+            float2 w16[16];
             auto put = [&](const float2 *v, int r, int base, int stride, int it) {
-                float2 wv[8];
-                ladder_expand(it == 0 ? la : lb_, wv);
+                if (it == 0) ladder16_expand(l16, w16);        // once per item: the runs are unrolled, `it` is a constant
                 const int c = base & (C - 1), jb = base >> LOG2C;
-                float2 *dst = Yr + (size_t)rev_n1<LOG2N1>(jb) * N2 + (tile * C + c);      // k1 = rev(jb) + 16 i
+                float2 *dst = Yr + (size_t)rev_n1<LOG2N1>(jb) * N2 + (tile * C + c);      // k1 = rev(jb) + (i << KSH)
 #pragma unroll
-                for (int i = 0; i < 8; ++i) dst[(size_t)i * (N2 << 4)] = cmul(v[i], wv[i]);
+                for (int i = 0; i < RL; ++i) dst[(size_t)i * ((size_t)N2 << KSH)] = cmul(v[i], w16[(it << LRL) + i]);
             };
             col_fft<LOG2N1, -1, 0, decltype(put), decltype(get)>(T, tw.tw1, tid, put, get);
             if (wn < nwork) issue_ladder(wn, tid);
@@ -366,10 +376,12 @@ __global__ __launch_bounds__(THREADS, 4) void k_long_inv_cols(const float2 *__re
     constexpr int PAIRS = TILE / 2 / THREADS;
     constexpr bool LADDER = LOG2N1 >= 3;
     constexpr int LOG2S = LADDER ? LOG2N1 - 3 : 0;
-    // STREAM (N1 = 128: radix 16 x 8): the first pass takes its inputs from global memory -- a thread's radix-16 group is one
-    // column in the tile rows r + 8 i: 16 loads of 8 bytes that a wave lays down as 512 contiguous bytes per k1 -- times their
-    // twiddles (a four-level ladder), instead of filling the tile first: one tile write, one barrier and one tile read less
-    constexpr bool STREAM = LOG2N1 == 7;
+    // STREAM (N1 >= 16: the first pass is a radix 16 with stride M = N1 / 16 rows): it takes its inputs from global memory -- a
+    // thread's group is one column in the tile rows r + M i: 16 loads of 8 bytes that a wave lays down as contiguous runs per
+    // k1 -- times their twiddles (a four-level ladder), instead of filling the tile first: one tile write, one barrier and one
+    // tile read less
+    constexpr bool STREAM = LOG2N1 >= 4;
+    constexpr int M0 = STREAM ? N1 / 16 : 1;
     float4 z[PAIRS];
     float2 zz[STREAM ? 16 : 1];
     Ladder la, lb_;
@@ -382,7 +394,7 @@ __global__ __launch_bounds__(THREADS, 4) void k_long_inv_cols(const float2 *__re
         if constexpr (STREAM) {
             const int c = tid & (C - 1), r = tid >> LOG2C;
 #pragma unroll
-            for (int i = 0; i < 16; ++i) zz[i] = Zr[(size_t)(r + 8 * i) * N2 + tile * C + c];
+            for (int i = 0; i < 16; ++i) zz[i] = Zr[(size_t)(r + M0 * i) * N2 + tile * C + c];
             return;
         }
 #pragma unroll
@@ -399,7 +411,7 @@ __global__ __launch_bounds__(THREADS, 4) void k_long_inv_cols(const float2 *__re
     auto issue_tw = [&](int w, int tid) {
         const int tile = tile_of(w);
         if constexpr (STREAM) {
-            ladder16_issue(l16, tw, (uint32_t)(tile * C + (tid & (C - 1))), (uint32_t)(tid >> LOG2C), 8u, 16u, 32u, 64u);
+            ladder16_issue(l16, tw, (uint32_t)(tile * C + (tid & (C - 1))), (uint32_t)(tid >> LOG2C), (uint32_t)M0, 2u * M0, 4u * M0, 8u * M0);
         } else if constexpr (LADDER) {
             const uint32_t k0 = (uint32_t)(2 * tid) >> LOG2C, n2 = (uint32_t)(tile * C + ((2 * tid) & (C - 1)));
             ladder_issue(la, tw, n2, k0, 1u << LOG2S, 2u << LOG2S, 4u << LOG2S);
