@@ -471,8 +471,23 @@ __global__ __launch_bounds__(THREADS, 4) void k_long_inv_cols(const float2 *__re
         float bm = -1.0f;
         int bi = 0x7fffffff;
         // (a radix-16 last pass, N1 = 16 or 256, keeps the tile round trip: 16 outputs plus their indices in flight spilled 24-31 registers)
-        constexpr bool FROM_REGS = !OUTPUT && FftGeom<LOG2N1>::log2r(FftGeom<LOG2N1>::NPASS - 1) <= 3;
-        if constexpr (!FROM_REGS) {
+        constexpr bool SMALL_LAST = FftGeom<LOG2N1>::log2r(FftGeom<LOG2N1>::NPASS - 1) <= 3;
+        constexpr bool FROM_REGS = !OUTPUT && SMALL_LAST, EMIT = OUTPUT && SMALL_LAST && STREAM;
+        if constexpr (EMIT) {
+            // the apply pass: the first L samples quantised like cdsp::convto8bit (src/cdsp.cc:51-54) straight from the last pass's
+            // registers, one sample (two bytes) per lane: a wave's 64 columns of one time row are 128 contiguous bytes
+            int8_t *orow = out + (size_t)rowi * B;
+            auto emit = [&](const float2 *v, int r, int base, int stride, int) {
+#pragma unroll
+                for (int i = 0; i < r; ++i) {
+                    const int e = base + i * stride, j = e >> LOG2C, c = e & (C - 1), n1 = rev_n1<LOG2N1>(j);
+                    if (n1 < N1 / 2)
+                        *reinterpret_cast<uint16_t *>(orow + 2 * ((size_t)n1 * N2 + (size_t)(tile * C + c))) =
+                            (uint16_t)((uint32_t)(uint8_t)f32_to_i8(v[i].x) | ((uint32_t)(uint8_t)f32_to_i8(v[i].y) << 8));
+                }
+            };
+            col_fft<LOG2N1, +1, 0, decltype(emit), decltype(get)>(T, tw.tw1, tid, emit, get);
+        } else if constexpr (!FROM_REGS) {
             if constexpr (STREAM) col_fft<LOG2N1, +1, 0, NoSink, decltype(get)>(T, tw.tw1, tid, NoSink(), get);
             else col_fft<LOG2N1, +1>(T, tw.tw1, tid);
         } else {
@@ -490,7 +505,8 @@ __global__ __launch_bounds__(THREADS, 4) void k_long_inv_cols(const float2 *__re
             else if (!LB_DBG(1)) col_fft<LOG2N1, +1, 0, decltype(take)>(T, tw.tw1, tid, take);
         }
         if (wn < nwork) issue_tw(wn, tid);                                   // table entries (cache hits): under the reduction below
-        if constexpr (OUTPUT) {
+        if constexpr (EMIT) {
+        } else if constexpr (OUTPUT) {
             int8_t *orow = out + (size_t)rowi * B;
             for (int e = 2 * tid; e < TILE; e += 2 * THREADS) {          // column pairs: one 32-bit store = samples n, n + 1
                 const int j = e >> LOG2C, c = e & (C - 1), n1 = rev_n1<LOG2N1>(j);
