@@ -3,6 +3,7 @@ block size (every power of two from 16 to 2^17, i.e. generic, 16384 and long-blo
 batch length, lag masks, refnoise gate, locked blocks, offset-binary input, readcnt words and row slabs.
 Deterministic (fixed seeds); the bars are those of tests/test_gpu_plan.py."""
 import importlib
+import os
 
 import numpy as np
 import pytest
@@ -43,6 +44,7 @@ def _check_block(got, exp, own, strong, tag, clean):
 
 @pytest.mark.parametrize("seed", range(96))
 def test_random_configuration_matches_the_oracle(b, oracle, synth, seed):
+    seed += int(os.environ.get("CRSDR_FUZZ_BASE", "0"))      # another 96 configurations: CRSDR_FUZZ_BASE=10000 pytest ...
     rng = np.random.default_rng(1000 + seed)
     log2B = int(rng.integers(4, 18)) if seed % 4 else int(rng.choice([14, 14, 15, 16]))
     B, L = 1 << log2B, 1 << (log2B - 1)
