@@ -718,7 +718,7 @@ def test_phase_path_variants_are_bit_identical(tmp_path):
         sys.path.insert(0, %r)
         pkg = importlib.import_module("coherent-rtlsdr_amd")
         b, synth = pkg.binding, pkg.synth
-        nsig, L, T = 300, 8192, 8
+        nsig, L, T = 300, 8192, 16
         params = synth.RowParams(nsig, L, 777, dmax=1500)
         blocks = np.stack([synth.make_block(nsig, L, 777, t, params=params)[0] for t in range(T)])
         blocks[3, 7] = 0                                  # a zero row in one block: "hold the previous phasor"
@@ -733,13 +733,15 @@ def test_phase_path_variants_are_bit_identical(tmp_path):
                  lag=np.stack([r["lag"] for r in res]), mag=np.stack([r["mag"] for r in res]))
     ''') % root
     outs = {}
-    for name, env in (("fused", {}), ("fallback", {"CRSDR_K2_SPIN": "-1"}), ("three", {"CRSDR_K2_FUSED": "0"}),
+    # ("nopoll": one look at the hand-over words and no waiting -- whatever an earlier block has published by then, its chain
+    # value or only its unit phasor, is used, everything else recomputed locally: every mix of the three sources in one run)
+    for name, env in (("fused", {}), ("fallback", {"CRSDR_K2_SPIN": "-1"}), ("nopoll", {"CRSDR_K2_SPIN": "0"}), ("three", {"CRSDR_K2_FUSED": "0"}),
                       ("overlap", {"CRSDR_OVERLAP": "1"})):            # K1 of the next batch beside this batch's phase kernel
         out = tmp_path / f"{name}.npz"
         r = subprocess.run([sys.executable, "-c", code, str(out)], env=dict(os.environ, **env), capture_output=True, text=True, timeout=300)
         assert r.returncode == 0, r.stdout + r.stderr
         outs[name] = np.load(out)
-    for other in ("fallback", "three", "overlap"):
+    for other in ("fallback", "nopoll", "three", "overlap"):
         for key in ("phasor", "packet", "lag", "mag"):
             assert np.array_equal(outs["fused"][key].view(np.uint8), outs[other][key].view(np.uint8)), (other, key)
 
