@@ -354,24 +354,27 @@ static hipError_t launch_long_fwd_cols(hipStream_t s, int nrows_launch, const in
 }
 // stage B with two lines per CU in opposite phases (k_rows14_cf32q): a line's HBM phases run beside the other line's transforms
 static hipError_t launch_long_rows_q(hipStream_t s, int n1, int nrows_launch, float2 *Y, const float2 *twA, const float2 *twB, float2 *refspec,
-                                     int *waitflag, unsigned int *work, unsigned int *work_base)
+                                     int *waitflag, unsigned int *work, unsigned int *work_base, const x14p::RampArgs *ramp = nullptr)
 {
     static const int cus = [] {
         int dev = 0, n = 0;
         if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 1) n = 256;
         return n;
     }();
-    auto kq = x14p::k_rows14_cf32q;
+    auto kq = ramp ? x14p::k_rows14_cf32q<true> : x14p::k_rows14_cf32q<false>;
     hipError_t e = hipFuncSetAttribute((const void *)kq, hipFuncAttributeMaxDynamicSharedMemorySize, x14p::LDSQ_BYTES);
     if (e != hipSuccess) return e;
     const int items = n1 * nrows_launch;
     static const int qspin = [] { const char *ev = getenv("CRSDR_K1_QSPIN"); return ev ? atoi(ev) : x14p::kQSpinLimit; }();
     static const int xcdq = [] { const char *ev = getenv("CRSDR_LONG_XCDQ"); return ev ? atoi(ev) : 1; }();      // 0: one queue, lines in memory order
     const int grid = std::max(1, std::min(cus, (items + 1) / 2));
-    const int nq = (xcdq && n1 % 8 == 0 && grid % 8 == 0) ? 8 : 1;       // one queue per XCD (k_rows14_cf32q); static order: the work counter is not used
+    // one queue per XCD (k_rows14_cf32q); static order: the work counter is not used.  (The apply pass's per-row spectra are
+    // 2.7 MB for cfg5 and stay in every L2: lines in memory order there.)
+    const int nq = (!ramp && xcdq && n1 % 8 == 0 && grid % 8 == 0) ? 8 : 1;
     (void)work; (void)work_base;
     hipLaunchKernelGGL(kq, dim3((unsigned)grid), dim3(2 * x14p::QG), x14p::LDSQ_BYTES, s, reinterpret_cast<c2 *>(Y),
-                       reinterpret_cast<const c2 *>(twA), reinterpret_cast<const c2 *>(twB), (const float4 *)refspec, n1, nrows_launch, nq, waitflag, qspin);
+                       reinterpret_cast<const c2 *>(twA), reinterpret_cast<const c2 *>(twB), (const float4 *)refspec, n1, nrows_launch, nq, waitflag, qspin,
+                       ramp ? *ramp : x14p::RampArgs{});
     return hipGetLastError();
 }
 // stage B: the 16384-point row transforms run on the 32x32x16 structure of xcorr14.hpp
@@ -754,6 +757,7 @@ struct crsdr_plan {
     float frac_gain = 1.0f;
     float *d_frac_override = nullptr;   // [nrows]
     uint32_t *d_k2tab = nullptr;        // [8192] frequency index k2 of every junction register pair of the row transforms
+    float4 *d_rowspec = nullptr;        // [row_count][8192] the rows' responses G(k2) in the junction's order (k_ramp_rowspec); allocated by set_frac_apply
     // pinned staging ring for the small per-batch host arrays
     uint32_t *h_readcnt = nullptr;
     uint8_t *h_mask = nullptr;
@@ -919,7 +923,7 @@ static void plan_free(crsdr_plan *p)
     if (p->xs) (void)hipStreamSynchronize(p->xs);
     if (p->cs) { (void)hipStreamSynchronize(p->cs); (void)hipStreamDestroy(p->cs); }
     for (auto e : p->ev_copydone) if (e) (void)hipEventDestroy(e);
-    void *bufs[] = {p->d_frac_override, p->d_k2tab, p->d_wc, p->d_wf, p->d_tw1, p->d_Y, p->d_Yref, p->d_part, p->d_tw, p->d_twA, p->d_twB, p->d_refspec[0], p->d_refspec[1], p->d_rows, p->d_packet_alloc, p->d_readcnt,
+    void *bufs[] = {p->d_rowspec, p->d_frac_override, p->d_k2tab, p->d_wc, p->d_wf, p->d_tw1, p->d_Y, p->d_Yref, p->d_part, p->d_tw, p->d_twA, p->d_twB, p->d_refspec[0], p->d_refspec[1], p->d_rows, p->d_packet_alloc, p->d_readcnt,
                     p->d_mask, p->d_lag, p->d_mag, p->d_frac, p->d_phasor, p->d_corr, p->d_sync, p->d_state, p->d_state_snap};
     for (void *b : bufs) if (b) (void)hipFree(b);
     if (p->h_k1flag) (void)hipHostFree(p->h_k1flag);
@@ -1082,6 +1086,7 @@ extern "C" int crsdr_plan_set_frac_apply(crsdr_plan *p, int enable, float gain, 
         if (rc) return rc;
         HIP_TRY(hipMemcpy(p->d_frac_override, frac_override, sizeof(float) * (size_t)p->nrows, hipMemcpyHostToDevice));
     }
+    if (!p->d_rowspec) HIP_TRY(hipMalloc((void **)&p->d_rowspec, sizeof(float4) * 8192 * (size_t)p->row_count));
     p->frac_apply = true; p->frac_gain = gain; p->frac_override_on = frac_override != nullptr;
     return CRSDR_OK;
 }
@@ -1397,7 +1402,22 @@ extern "C" int crsdr_plan_submit_batch(crsdr_plan *p, const void *rows, int mem_
                 float2 *Yc = p->d_Y + (size_t)r0 * (size_t)p->B;
                 x14p::RampArgs ra{o_lag, o_frac, p->frac_override_on ? p->d_frac_override : nullptr, p->d_phasor, p->d_k2tab, p->d_wc, p->d_wf, lb::FBITS, p->frac_gain, p->row_begin + r0, l1};
                 HIP_TRY(CRSDR_DISPATCH_N1(l1, (launch_long_fwd_cols<LG, false>(S, cnt, d_in, p->row_begin + r0, xor80, tw, Yc))));
-                HIP_TRY(launch_long_rows_ramp(S, n1, cnt, Yc, p->d_twA, p->d_twB, ra));
+                // stage B'': two lines per CU with the rows' responses as per-row spectra (k_ramp_rowspec + k_rows14_cf32q<true>) once a
+                // launch has enough lines; the one-line kernel that forms the response per bin otherwise
+                static const int longq2 = [] { const char *e = getenv("CRSDR_LONG_Q"); return e ? atoi(e) : 1; }();
+                const char kv2 = k1_variant();
+                if (longq2 && (kv2 == 'a' || kv2 == 'q') && !p->q_disabled && (long)n1 * cnt >= 1024) {
+                    hipLaunchKernelGGL(x14p::k_ramp_rowspec, dim3(8192 / 256, cnt), dim3(256), 0, S, p->d_rowspec + (size_t)r0 * 8192, ra);
+                    HIP_TRY(hipGetLastError());
+                    if (!p->snap_valid) {                  // (the same rollback protocol as the correlation pass)
+                        p->snap_valid = true; p->snap_phase_cur = p->phase_cur;
+                        HIP_TRY(hipMemcpyAsync(p->d_state_snap, p->d_state, p->state_bytes, hipMemcpyDeviceToDevice, S));
+                    }
+                    HIP_TRY(launch_long_rows_q(S, n1, cnt, Yc, p->d_twA, p->d_twB, reinterpret_cast<float2 *>(p->d_rowspec + (size_t)r0 * 8192),
+                                               reinterpret_cast<int *>(p->d_sync + 2), p->d_sync + 3, &p->q_work_base, &ra));
+                    p->k1_used = true;
+                } else
+                    HIP_TRY(launch_long_rows_ramp(S, n1, cnt, Yc, p->d_twA, p->d_twB, ra));
                 HIP_TRY(CRSDR_DISPATCH_N1(l1, (launch_long_out_cols<LG>(S, cnt, Yc, tw, obase + (size_t)r0 * (size_t)p->B))));
             }
         }

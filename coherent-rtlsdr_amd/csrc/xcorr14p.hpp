@@ -426,6 +426,42 @@ struct RampArgs {
     float gain;
     int row0, log2n1;          // global row of blockIdx.y == 0
 };
+// The response factored for the two-line stage-B kernel (k_rows14_cf32q<true>): with k = k1 + N1 k2
+//     H[k] = c(k1) . G(k2),   c = p / B . exp(2 pi i k1 (lag + D) / B),   G = exp(2 pi i k2 lag / 16384) . exp(2 pi i (k2 D / 16384 - [k2 >= 8192] D))
+// G does not depend on the line: it is written once per row and block as a "spectrum" of the row in the junction's register
+// order (128 KiB per row: the 128 lines of a row read it from L2 exactly as the correlation pass reads the reference
+// spectrum), and c scales a line's inputs.  The per-bin work of the junction -- two gathers, a polynomial sine / cosine and
+// four products, two thirds of the one-line kernel's time -- is then done once per row instead of once per line.
+__device__ __forceinline__ c2 ramp_line_scale(const RampArgs &ra, int row, uint32_t k1)
+{
+    const int log2B = 14 + ra.log2n1;
+    const uint32_t bmask = (1u << log2B) - 1u, lagu = (uint32_t)ra.lag[row];
+    const float invB = 1.0f / (float)(1u << log2B);
+    const float D = ra.frac_override ? ra.frac_override[row] : ra.gain * ra.frac[row];
+    const float2 pr = ra.phasor[row];
+    const uint32_t m1 = (k1 * lagu) & bmask;
+    const float2 a = ra.wc[m1 >> ra.fbits], f = ra.wf[m1 & ((1u << ra.fbits) - 1u)];
+    return cmul(cmulc(mk(pr.x * invB, pr.y * invB), cmul(mk(a.x, a.y), mk(f.x, f.y))), cis2pi((float)k1 * (D * invB)));
+}
+// grid (8192 / 256, rows of the launch); G + (row in launch) * 8192 float4
+__global__ __launch_bounds__(256) void k_ramp_rowspec(float4 *__restrict__ G, RampArgs ra)
+{
+    const int idx = blockIdx.x * 256 + threadIdx.x, row = ra.row0 + (int)blockIdx.y;
+    const uint32_t lagu = (uint32_t)ra.lag[row];
+    const float D = ra.frac_override ? ra.frac_override[row] : ra.gain * ra.frac[row];
+    const uint32_t kk = ra.k2tab[idx];
+    float hx[4];
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        const uint32_t k2 = e ? (kk >> 16) : (kk & 0xffffu);
+        const uint32_t m2 = ((k2 * lagu) & 16383u) << ra.log2n1;                       // W_16384^x = W_B^(N1 x): the plan's two-level table
+        const float2 a = ra.wc[m2 >> ra.fbits], f = ra.wf[m2 & ((1u << ra.fbits) - 1u)];
+        const c2 h = cmulc(cis2pi((float)k2 * (D * (1.0f / 16384.0f)) - (k2 >= 8192u ? D : 0.0f)), cmul(mk(a.x, a.y), mk(f.x, f.y)));
+        hx[2 * e] = h.x; hx[2 * e + 1] = h.y;
+    }
+    G[(size_t)blockIdx.y * 8192 + idx] = make_float4(hx[0], hx[1], hx[2], hx[3]);
+}
+
 template <bool IS_REF, bool RAMP = false>
 __global__ __launch_bounds__(THREADS, 2) void k_rows14_cf32p(c2 *__restrict__ Y, const c2 *__restrict__ twA,
                                                              const c2 *__restrict__ twB, float4 *__restrict__ refspec_base, RampArgs ra = RampArgs{})

@@ -413,9 +413,12 @@ __device__ __forceinline__ void q_line_store2(c2 *__restrict__ line, const c2 *v
 // on XCD b % 8 (round-robin dispatch) and takes lines with k1 % 8 == b % 8, k1-major, so that the rows of one k1 pass through
 // one L2 at about the same time and its slice is fetched once per launch and XCD.  (The mapping only matters for speed: whatever
 // XCD a workgroup really runs on, every line is done exactly once.)  nq = 8 when n1 and the grid are multiples of 8, else 1.
+// RAMP (the apply pass of crsdr_plan_set_frac_apply): the "spectrum" is the row's own response G (k_ramp_rowspec: one 128 KiB
+// slice per row of the launch) and a line's inputs are scaled by its c(k1) -- the same kernel otherwise.
+template <bool RAMP>
 __global__ __launch_bounds__(2 * QG, 1) void k_rows14_cf32q(c2 *__restrict__ Y, const c2 *__restrict__ twA, const c2 *__restrict__ twB,
                                                            const float4 *__restrict__ refspec_base, int n1, int rows, int nq, int *__restrict__ errflag,
-                                                           int spin_limit)
+                                                           int spin_limit, RampArgs ra)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     c2 *A = reinterpret_cast<c2 *>(smem);
@@ -438,7 +441,7 @@ __global__ __launch_bounds__(2 * QG, 1) void k_rows14_cf32q(c2 *__restrict__ Y, 
 #ifdef CRSDR_B_SPEC0      // diagnostic: every line reads spectrum slice 0 (wrong results; what the slices' traffic costs)
         const float4 *__restrict__ refspec4 = refspec_base;
 #else
-        const float4 *__restrict__ refspec4 = refspec_base + (size_t)(item_u % n1) * (N / 2);
+        const float4 *__restrict__ refspec4 = refspec_base + (size_t)(RAMP ? item_u / n1 : item_u % n1) * (N / 2);
 #endif
         c2 wB[32];
         {
@@ -450,6 +453,11 @@ __global__ __launch_bounds__(2 * QG, 1) void k_rows14_cf32q(c2 *__restrict__ Y, 
             // as it was with both halves' loads issued up front, 97.0: this stage is not waiting for its memory instructions.)
             const int pc0 = 2 * vt0, pc1 = 2 * vt0 + 1;
             q_line_load2(v, v2, line, vt0);
+            if constexpr (RAMP) {
+                const c2 cl = ramp_line_scale(ra, ra.row0 + item_u / n1, (uint32_t)(item_u % n1));
+#pragma unroll
+                for (int i = 0; i < 32; ++i) { v[i] = cmul(v[i], cl); v2[i] = cmul(v2[i], cl); }
+            }
             __builtin_amdgcn_sched_barrier(0);
             q_line_p0_transform(v, twA, pc0);
             __builtin_amdgcn_sched_barrier(0);
