@@ -354,7 +354,7 @@ static hipError_t launch_long_fwd_cols(hipStream_t s, int nrows_launch, const in
 }
 // stage B with two lines per CU in opposite phases (k_rows14_cf32q): a line's HBM phases run beside the other line's transforms
 static hipError_t launch_long_rows_q(hipStream_t s, int n1, int nrows_launch, float2 *Y, const float2 *twA, const float2 *twB, float2 *refspec,
-                                     int *waitflag, unsigned int *work, unsigned int *work_base, const x14p::RampArgs *ramp = nullptr)
+                                     int *waitflag, unsigned int *work, unsigned int *work_base, const x14p::RampArgs *ramp = nullptr, float2 *Yout = nullptr)
 {
     static const int cus = [] {
         int dev = 0, n = 0;
@@ -374,7 +374,7 @@ static hipError_t launch_long_rows_q(hipStream_t s, int n1, int nrows_launch, fl
     (void)work; (void)work_base;
     hipLaunchKernelGGL(kq, dim3((unsigned)grid), dim3(2 * x14p::QG), x14p::LDSQ_BYTES, s, reinterpret_cast<c2 *>(Y),
                        reinterpret_cast<const c2 *>(twA), reinterpret_cast<const c2 *>(twB), (const float4 *)refspec, n1, nrows_launch, nq, waitflag, qspin,
-                       ramp ? *ramp : x14p::RampArgs{});
+                       ramp ? *ramp : x14p::RampArgs{}, reinterpret_cast<c2 *>(Yout));
     return hipGetLastError();
 }
 // stage B: the 16384-point row transforms run on the 32x32x16 structure of xcorr14.hpp
@@ -757,6 +757,7 @@ struct crsdr_plan {
     float frac_gain = 1.0f;
     float *d_frac_override = nullptr;   // [nrows]
     uint32_t *d_k2tab = nullptr;        // [8192] frequency index k2 of every junction register pair of the row transforms
+    float2 *d_Z = nullptr;              // second work area (set_frac_apply): the correlation pass's stage B writes here, so that the apply pass finds stage A's output still in d_Y
     float4 *d_rowspec = nullptr;        // [row_count][8192] the rows' responses G(k2) in the junction's order (k_ramp_rowspec); allocated by set_frac_apply
     // pinned staging ring for the small per-batch host arrays
     uint32_t *h_readcnt = nullptr;
@@ -923,7 +924,7 @@ static void plan_free(crsdr_plan *p)
     if (p->xs) (void)hipStreamSynchronize(p->xs);
     if (p->cs) { (void)hipStreamSynchronize(p->cs); (void)hipStreamDestroy(p->cs); }
     for (auto e : p->ev_copydone) if (e) (void)hipEventDestroy(e);
-    void *bufs[] = {p->d_rowspec, p->d_frac_override, p->d_k2tab, p->d_wc, p->d_wf, p->d_tw1, p->d_Y, p->d_Yref, p->d_part, p->d_tw, p->d_twA, p->d_twB, p->d_refspec[0], p->d_refspec[1], p->d_rows, p->d_packet_alloc, p->d_readcnt,
+    void *bufs[] = {p->d_Z, p->d_rowspec, p->d_frac_override, p->d_k2tab, p->d_wc, p->d_wf, p->d_tw1, p->d_Y, p->d_Yref, p->d_part, p->d_tw, p->d_twA, p->d_twB, p->d_refspec[0], p->d_refspec[1], p->d_rows, p->d_packet_alloc, p->d_readcnt,
                     p->d_mask, p->d_lag, p->d_mag, p->d_frac, p->d_phasor, p->d_corr, p->d_sync, p->d_state, p->d_state_snap};
     for (void *b : bufs) if (b) (void)hipFree(b);
     if (p->h_k1flag) (void)hipHostFree(p->h_k1flag);
@@ -1087,6 +1088,10 @@ extern "C" int crsdr_plan_set_frac_apply(crsdr_plan *p, int enable, float gain, 
         HIP_TRY(hipMemcpy(p->d_frac_override, frac_override, sizeof(float) * (size_t)p->nrows, hipMemcpyHostToDevice));
     }
     if (!p->d_rowspec) HIP_TRY(hipMalloc((void **)&p->d_rowspec, sizeof(float4) * 8192 * (size_t)p->row_count));
+    if (!p->d_Z && hipMalloc((void **)&p->d_Z, sizeof(float2) * (size_t)p->B * (size_t)p->row_count) != hipSuccess) {
+        p->d_Z = nullptr;                  // no room for a second work area: the apply pass repeats stage A instead
+        (void)hipGetLastError();
+    }
     p->frac_apply = true; p->frac_gain = gain; p->frac_override_on = frac_override != nullptr;
     return CRSDR_OK;
 }
@@ -1212,6 +1217,7 @@ extern "C" int crsdr_plan_submit_batch(crsdr_plan *p, const void *rows, int mem_
     // slots from K1's two waves per SIMD rather than filling their stalls.  Off by default.
     const bool use_x = p->overlap && fused && any_lag && !p->longblock;
     bool corr_zeroed = false;
+    bool kept_fwd = false;                        // long blocks: stage A's output survived the correlation pass (in d_Y; stage B wrote d_Z)
     hipStream_t KS = use_x ? p->xs : S;
 
     if (any_lag && p->longblock) {
@@ -1243,6 +1249,15 @@ extern "C" int crsdr_plan_submit_batch(crsdr_plan *p, const void *rows, int mem_
         xa.lag_state = p->d_lag_state; xa.mag_state = p->d_mag_state; xa.frac_state = p->d_frac_state;
         hipEvent_t *pe1 = prof_pair(p, CRSDR_KERNEL_XCORR_LAG);
         if (pe1) HIP_TRY(hipEventRecord(pe1[0], S));
+        // with the fractional-delay pass to follow, stage B writes into the second work area: stage A's output stays in d_Y and
+        // the apply pass does not repeat it (73 us of a 770 us cfg5 block) -- for the whole block or not at all (two-line kernel only)
+        {
+            static const int longq0 = [] { const char *e = getenv("CRSDR_LONG_Q"); return e ? atoi(e) : 1; }();
+            const char kv0 = k1_variant();
+            kept_fwd = p->d_Z && p->frac_apply && aa.digital && longq0 && (kv0 == 'a' || kv0 == 'q') && !p->q_disabled;
+            for (int r0 = 0; r0 < p->row_count; r0 += p->long_chunk)
+                kept_fwd = kept_fwd && (long)n1 * std::min(p->long_chunk, p->row_count - r0) >= 1024;
+        }
         // rows go through the three stages in chunks whose cf32 work area fits the 256 MB memory-side cache
         for (int r0 = 0; r0 < p->row_count; r0 += p->long_chunk) {
             const int cnt = std::min(p->long_chunk, p->row_count - r0);
@@ -1252,21 +1267,24 @@ extern "C" int crsdr_plan_submit_batch(crsdr_plan *p, const void *rows, int mem_
             // (and always under CRSDR_K1_VARIANT=packed|scalar, or after a bounded wait of the two-line kernels ran out)
             static const int longq = [] { const char *e = getenv("CRSDR_LONG_Q"); return e ? atoi(e) : 1; }();
             const char kv = k1_variant();
-            if (longq && (kv == 'a' || kv == 'q') && !p->q_disabled && (long)n1 * cnt >= 1024) {
+            const bool useq = longq && (kv == 'a' || kv == 'q') && !p->q_disabled && (long)n1 * cnt >= 1024;
+            float2 *Zc = kept_fwd ? p->d_Z + (size_t)r0 * (size_t)p->B : Yc;
+            if (useq) {
                 if (!p->snap_valid) {                      // same rollback protocol as the two-row K1 (check_fused_status)
                     p->snap_valid = true; p->snap_phase_cur = p->phase_cur;
                     HIP_TRY(hipMemcpyAsync(p->d_state_snap, p->d_state, p->state_bytes, hipMemcpyDeviceToDevice, S));
                 }
-                HIP_TRY(launch_long_rows_q(S, n1, cnt, Yc, p->d_twA, p->d_twB, p->d_refspec[slot], reinterpret_cast<int *>(p->d_sync + 2), p->d_sync + 3, &p->q_work_base));
+                HIP_TRY(launch_long_rows_q(S, n1, cnt, Yc, p->d_twA, p->d_twB, p->d_refspec[slot], reinterpret_cast<int *>(p->d_sync + 2), p->d_sync + 3, &p->q_work_base,
+                                           nullptr, Zc != Yc ? Zc : nullptr));
                 p->k1_used = true;
             } else
                 HIP_TRY(launch_long_rows<false>(S, n1, cnt, Yc, p->d_twA, p->d_twB, p->d_refspec[slot]));
-            HIP_TRY(CRSDR_DISPATCH_N1(l1, (launch_long_inv_cols<LG>(S, cnt, Yc, tw, p->d_part + (size_t)r0 * lb::ntiles(l1)))));
+            HIP_TRY(CRSDR_DISPATCH_N1(l1, (launch_long_inv_cols<LG>(S, cnt, Zc, tw, p->d_part + (size_t)r0 * lb::ntiles(l1)))));
         }
         HIP_TRY(hipEventRecord(p->ev_k1done[slot], S));       // the last reader of this block's reference spectrum has been enqueued
         p->k1done_valid[slot] = true;
         corr_zeroed = aa.refnoise && !fused && chunks > 1 && nblocks == 1;      // (the three-kernel path's integer sums: see below)
-        hipLaunchKernelGGL(lb::k_long_finalize, dim3(p->row_count), dim3(256), 0, S, p->d_Y, p->d_part, tw, n1, lb::ntiles(l1), xa, corr_zeroed ? p->d_corr : nullptr);
+        hipLaunchKernelGGL(lb::k_long_finalize, dim3(p->row_count), dim3(256), 0, S, kept_fwd ? p->d_Z : p->d_Y, p->d_part, tw, n1, lb::ntiles(l1), xa, corr_zeroed ? p->d_corr : nullptr);
         HIP_TRY(hipGetLastError());
         if (pe1) HIP_TRY(hipEventRecord(pe1[1], S));
     } else if (any_lag) {
@@ -1401,7 +1419,7 @@ extern "C" int crsdr_plan_submit_batch(crsdr_plan *p, const void *rows, int mem_
                 const int cnt = std::min(p->long_chunk, p->row_count - r0);
                 float2 *Yc = p->d_Y + (size_t)r0 * (size_t)p->B;
                 x14p::RampArgs ra{o_lag, o_frac, p->frac_override_on ? p->d_frac_override : nullptr, p->d_phasor, p->d_k2tab, p->d_wc, p->d_wf, lb::FBITS, p->frac_gain, p->row_begin + r0, l1};
-                HIP_TRY(CRSDR_DISPATCH_N1(l1, (launch_long_fwd_cols<LG, false>(S, cnt, d_in, p->row_begin + r0, xor80, tw, Yc))));
+                if (!kept_fwd) HIP_TRY(CRSDR_DISPATCH_N1(l1, (launch_long_fwd_cols<LG, false>(S, cnt, d_in, p->row_begin + r0, xor80, tw, Yc))));
                 // stage B'': two lines per CU with the rows' responses as per-row spectra (k_ramp_rowspec + k_rows14_cf32q<true>) once a
                 // launch has enough lines; the one-line kernel that forms the response per bin otherwise
                 static const int longq2 = [] { const char *e = getenv("CRSDR_LONG_Q"); return e ? atoi(e) : 1; }();

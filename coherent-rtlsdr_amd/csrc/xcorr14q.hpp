@@ -418,7 +418,7 @@ __device__ __forceinline__ void q_line_store2(c2 *__restrict__ line, const c2 *v
 template <bool RAMP>
 __global__ __launch_bounds__(2 * QG, 1) void k_rows14_cf32q(c2 *__restrict__ Y, const c2 *__restrict__ twA, const c2 *__restrict__ twB,
                                                            const float4 *__restrict__ refspec_base, int n1, int rows, int nq, int *__restrict__ errflag,
-                                                           int spin_limit, RampArgs ra)
+                                                           int spin_limit, RampArgs ra, c2 *__restrict__ Yout)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     c2 *A = reinterpret_cast<c2 *>(smem);
@@ -438,6 +438,7 @@ __global__ __launch_bounds__(2 * QG, 1) void k_rows14_cf32q(c2 *__restrict__ Y, 
         if (j >= nqueue) break;
         const int item_u = __builtin_amdgcn_readfirstlane((j % rows) * n1 + (j / rows) * nq + q);      // line index in Y: row * n1 + k1 (scalar base addresses)
         c2 *line = Y + (size_t)item_u * N;
+        c2 *line_out = Yout ? Yout + (size_t)item_u * N : line;      // out of place when the caller keeps the forward column transforms (the apply pass reuses them)
 #ifdef CRSDR_B_SPEC0      // diagnostic: every line reads spectrum slice 0 (wrong results; what the slices' traffic costs)
         const float4 *__restrict__ refspec4 = refspec_base;
 #else
@@ -496,7 +497,7 @@ __global__ __launch_bounds__(2 * QG, 1) void k_rows14_cf32q(c2 *__restrict__ Y, 
             __builtin_amdgcn_sched_barrier(0);
             q_line_p0i_transform(v2, twA, 2 * vs0 + 1);
             __builtin_amdgcn_sched_barrier(0);
-            q_line_store2(line, v, v2, vs0);
+            q_line_store2(line_out, v, v2, vs0);
         }
     }
     if (threadIdx.x == 0 && errflag) {
