@@ -209,7 +209,9 @@ int crsdr_plan_fetch_block(crsdr_plan *plan, int block, int32_t *lag, float *mag
  * the frequency domain: X[f] * exp(+2 pi i f_s (lag_k + D_k) / B), f_s the signed bin index -- then rotated by the phasor
  * and quantised like cdsp::convto8bit; for D = 0 that is the digital mode's zero-filled integer shift.
  *   D_k = frac_override[k] if given (host [nrows], copied; entry 0 ignored), else gain * frac_k (this block's estimate).
- * lag / mag / frac / phasor outputs are unchanged (the phase is still estimated on the integer-aligned row). */
+ * lag / mag / frac / phasor outputs are unchanged (the phase is still estimated on the integer-aligned row).
+ * Enabling it allocates (once, here -- never on the per-block path) a second cf32 work area of 8 * blocksize bytes per owned row and
+ * 128 KiB per owned row for the rows' response spectra; if the work area cannot be had the pass repeats its first stage instead. */
 int crsdr_plan_set_frac_apply(crsdr_plan *plan, int enable, float gain, const float *frac_override);
 
 /* Pipelined fetch of the LAST submitted batch into page-locked host memory (crsdr_host_alloc): the device-to-host copies
