@@ -96,17 +96,18 @@ def main():
     mode = b.MODE_DIGITAL if args.mode == "digital" else b.MODE_FAITHFUL
 
     # ---- synthetic resident input: nbuf distinct blocks, each rank fills row 0 + its slab ----------
-    # blocks per submit: the plan's maximum (64) when the timed region is long enough for >= 4 whole batches; for a short
-    # region (the driver's --steps 20) one GPU keeps the whole region in ONE launch set (its steady-state rate: the region is
-    # repeated and the median reported), several GPUs take T = a multiple of the world size with >= 4 whole batches where the
-    # step count allows (T = world at least: every rank roots T / world blocks of a batch), so that the exchange pipeline of the
-    # three ring-buffered sets is actually in flight inside the region.  A ragged last batch ships only its own bytes.
+    # blocks per submit: ONE batch per timed region when the region fits the plan's maximum of 64 blocks (the driver's
+    # --steps 20: T = 20 on one GPU and on eight), else batches of 64 (several GPUs: the largest multiple of the world size,
+    # so that every rank roots the same number of blocks).  Regions are issued back to back -- the series is fenced once, see
+    # `series()` -- so the three ring-buffered output sets keep region r's exchange under region r + 1's compute whatever T is;
+    # r02 sized T for ">= 4 batches inside one fenced region", which at --steps 20 on 8 GPUs meant 8 + 8 + 4 blocks and 91 us
+    # of fixed cost per batch.  A ragged last batch ships only its own bytes.
     if args.batch > 0:
         T = max(1, min(args.batch, 64))
-    elif world == 1:
-        T = max(1, min(64, args.steps))
+    elif args.steps <= 64:
+        T = max(1, args.steps)
     else:
-        T = max(world, min(64, (args.steps // 4) // world * world))
+        T = 64 if world == 1 else max(world, 64 // world * world)
     nbuf = max(2 * T if world > 1 else T, (args.nbuf // T) * T)   # whole batches, contiguous in HBM
     seed = synth.config_seed(4)
     params = synth.RowParams(nsig, L, seed)
@@ -143,9 +144,15 @@ def main():
         done = [None] * NSETS                          # event: set k's exchange + assembly finished
     xchg = {"c": None}                                 # crsdr_exchange (RCCL under the C ABI) when the C transport is selected
 
-    def run_batch(ib, nb, fl=flags):
-        """blocks [ib*T, ib*T + nb) of the stream: one submit; with several GPUs then ONE exchange of the batch's slots
+    gib = {"n": 0, "last_full": None}                  # batches issued so far: output sets, input blocks and seq keep rotating across regions
+
+    def run_batch(nb, fl=flags):
+        """the next nb blocks of the stream: one submit; with several GPUs then ONE exchange of the batch's slots
         (rank q assembles the q-th run of ceil(nb/G) blocks, rows AND per-row scalars) and the assembly on a side stream"""
+        ib = gib["n"]
+        gib["n"] = ib + 1
+        if nb == T:
+            gib["last_full"] = ib
         k = ib % NSETS
         first_buf = (ib * T) % nbuf
         if world == 1:
@@ -194,26 +201,42 @@ def main():
 
     def run_steps(nsteps, fl=flags):
         """exactly nsteps blocks, in batches of T (the last batch may be shorter)"""
-        ib, left = 0, nsteps
+        left = nsteps
         while left > 0:
             nb = min(T, left)
-            run_batch(ib, nb, fl)
-            ib, left = ib + 1, left - nb
+            run_batch(nb, fl)
+            left -= nb
 
-    host_issue = {}
+    def series(nsteps, regions, fl=flags):
+        """`regions` timed regions of exactly nsteps steps each, issued back to back.  The barrier (+ device sync) is BEFORE the
+        clock starts only; at the end every rank waits for ITS OWN last exchange and assembly (the `done` events, then a local
+        device sync) -- no collective inside the interval: r02 ended the interval with dist.barrier(), tens of microseconds of
+        RCCL latency charged to a 0.2 ms region.  The MAX over ranks is taken after the clocks have stopped.
+        Returns (host seconds, GPU-event seconds between the first submit and the last assembly, host seconds spent issuing)."""
+        fence()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
+        e0.record(stream)
+        for _ in range(regions):
+            run_steps(nsteps, fl)
+        t_issue = time.perf_counter() - t0              # host time to enqueue everything (no waiting on the GPU)
+        if world > 1:
+            for ev in done:
+                if ev is not None:
+                    stream.wait_event(ev)               # this rank's outstanding exchanges + assemblies
+        e1.record(stream)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        dt_ev = 1e-3 * e0.elapsed_time(e1)
+        if world > 1:
+            t = torch.tensor([dt, dt_ev, t_issue], device="cpu" if rehearsal else dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt, dt_ev, t_issue = (float(x) for x in t.tolist())
+        return dt, dt_ev, t_issue
 
     def timed(nsteps, fl=flags):
-        fence()
-        t0 = time.perf_counter()
-        run_steps(nsteps, fl)
-        host_issue["s"] = time.perf_counter() - t0       # host time to enqueue everything (no waiting on the GPU)
-        fence()
-        dt = time.perf_counter() - t0
-        if world > 1:
-            t = torch.tensor([dt], device="cpu" if rehearsal else dev, dtype=torch.float64)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            dt = float(t.item())
-        return dt
+        """one fenced region (what r01 / r02 reported the median of)"""
+        return series(nsteps, 1, fl)[0]
 
     # communicator set-up (not a step): RCCL opens its point-to-point channels lazily, on the first exchange
     # between each rank pair -- do that here, on the still-empty buffers, so that connection set-up cannot land
@@ -223,37 +246,36 @@ def main():
         torch.cuda.synchronize()
         dist.barrier()
 
-    # ---- warm-up, then the timed region with per-kernel HIP events on the launch streams ----------
+    # ---- warm-up, fenced regions (extras), then the timed series with HIP events on K1's launch stream ----------
     run_steps(args.warmup)
     fence()
-    # timed region: hipEvent pairs around the dominant kernel (K1) only -- every pair costs stream time.  The region of
-    # exactly --steps steps is repeated and the MEDIAN reported: a 1 ms region between two device-wide fences is noise-prone
-    # How many repeats: a device that has idled (the seconds of host-side input generation above) needs ~50 ms of sustained
-    # load before its clocks settle -- measured r02, `region_ms` of a 60-repeat run: 1.17, 1.19, 1.28, 1.25, 1.20 ... 0.99 ms
-    # for the same 20 steps -- so 5 repeats of a 1 ms region all sat inside that ramp.  The region is now repeated until
-    # ~250 ms of timed work have run (5 .. 400 repeats) and the median is what a busy device sustains; `region_ms` carries the
-    # series, `value_first5` the median of the first five repeats (what r01 / early r02 records reported).
+    # How much is timed: a device that has idled (the seconds of host-side input generation above) needs ~40 ms of sustained load
+    # before its clocks settle -- measured r02, `region_ms` of a 60-repeat run: 1.17, 1.19, 1.28, 1.25, 1.20 ... 0.99 ms for the
+    # same 20 steps.  So the region of exactly --steps steps is issued `repeats` times, ~250 ms of work (5 .. 400 regions):
+    #   (1) each between its own fences -- `value_fenced_median`, `region_ms` (the series in order), `value_first5` (the clock
+    #       ramp): what r01 / r02 reported, kept as extras; a fenced region pays its cold start (K0 exposed, launch gaps, the
+    #       drain of the last exchange) once per --steps steps;
+    #   (2) back to back, fenced ONCE around the whole series -- `value`: blocks per second of the stream the engine exists for,
+    #       in which region r's exchange / K0 of region r + 1 run under their neighbours' compute.
     nbatch = -(-args.steps // T)
     est_ms = args.steps * (0.55 if args.cfg5 else 0.05 * (nsig + 1) / 1025) / world
     repeats = args.repeats if args.repeats > 0 else int(min(400, max(5, -(-250.0 // max(est_ms, 1e-3)))))
     repeats = min(repeats, max(1, 4096 // nbatch))                    # one HIP-event pair per K1 launch
     if rehearsal and args.repeats <= 0:
         repeats = min(repeats, 5)                                     # bookkeeping run through host memory: its timing means nothing
-    plan.enable_profiling(min(max(nbatch * repeats, 1), 4096), 1 << b.KERNEL_XCORR_LAG)
     dts = [timed(args.steps) for _ in range(repeats)]
-    dt = float(np.median(dts))
-    # the repeats whose time lies in the central half of the distribution: K1's average launch duration is taken over THEIR
-    # launches, so that `roofline` and `value` describe the same state of the device
-    order = np.argsort(dts)
-    central = sorted(int(i) for i in order[len(order) // 4: len(order) - len(order) // 4])
+    # hipEvent pairs around the dominant kernel (K1) only -- every pair costs stream time
+    plan.enable_profiling(min(max(nbatch * repeats, 1), 4096), 1 << b.KERNEL_XCORR_LAG)
+    dt_series, dt_series_ev, t_issue = series(args.steps, repeats)
+    dt = dt_series / repeats                                          # per region of --steps steps
+    host_issue = {"s": t_issue / repeats}
     # checked right here, before later (untimed) runs reuse the packet sets: the last full batch -- every packet this rank
     # assembled must hold every rank's rows under the header of the right block, and its scalars block every rank's lags
     assembled_ok = scalars_ok = True
     if world > 1:
         torch.cuda.synchronize()
-        nfull = args.steps // T
-        if nfull:
-            ib = nfull - 1
+        if gib["last_full"] is not None and gib["n"] - gib["last_full"] <= NSETS:
+            ib = gib["last_full"]                    # the series' last full batch: its output set has not been reused (fewer than NSETS batches after it)
             mine = sharding.rooted_range(T, world, rank)
             for j, t_ in enumerate(mine):
                 pkv = pk_view[ib % NSETS][j]
@@ -285,7 +307,7 @@ def main():
     if world == 1:
         plan.enable_profiling(4, 0xF | (1 << 31))
         fence()
-        run_batch(0, T)
+        run_batch(T)
         fence()
         tot = plan.last_elapsed_ms()
         parts = [plan.kernel_times_ms(k) for k in (b.KERNEL_XCORR_LAG, b.KERNEL_PHASE_DOT, b.KERNEL_ALIGN_QUANT)]
@@ -301,8 +323,7 @@ def main():
     if rank == 0:
         A_block = nrows * B                                   # algorithmic bytes per block
         k1_all = k_ms["xcorr_lag"]
-        keep = set(central) if len(k1_all) == nbatch * repeats else set(range(repeats))
-        k1s = [x for i, x in enumerate(k1_all) if (i // nbatch) in keep and ((i % nbatch) < full_batches or not full_batches)]   # central repeats, launches that carried T blocks
+        k1s = [x for i, x in enumerate(k1_all) if ((i % nbatch) < full_batches or not full_batches)]   # the series' launches that carried T blocks
         k1 = float(np.mean(k1s)) if len(k1s) else float("nan")
         tb = T if full_batches else args.steps
         k1_bytes = tb * slab.row_count * B                    # int8 bytes one K1 launch consumes (tb blocks)
@@ -311,9 +332,16 @@ def main():
         result = {
             "metric": f"aligned IQ blocks/s ({nsig} ch x {L})", "value": blocks_per_s, "unit": "blocks/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
-            "repeats": repeats, "value_spread": [args.steps / max(dts), args.steps / min(dts)],     # the region is timed `repeats` times: value = median
-            "region_ms": [round(1e3 * dts[i], 4) for i in sorted(set(np.linspace(0, len(dts) - 1, min(len(dts), 48)).astype(int).tolist()))],   # the series in order (evenly thinned to <= 48 entries)
-            "value_first5": args.steps / float(np.median(dts[:5])),                                  # a device just out of idle: the ramp (see the comment at `repeats`)
+            "repeats": repeats,
+            "timing": {"clock": "host perf_counter around `repeats` back-to-back regions of --steps steps: barrier + device sync before t0 only, "
+                                "each rank's own device sync (after its last exchange + assembly) at the end, MAX over ranks taken afterwards",
+                       "regions": repeats, "steps_timed": args.steps * repeats, "series_ms": 1e3 * dt_series,
+                       "gpu_event_ms": 1e3 * dt_series_ev, "value_gpu_events": args.steps * repeats / dt_series_ev,
+                       "note": "gpu_event_ms: hipEvents on the compute stream from the first submit to after the last assembly"},
+            "value_fenced_median": args.steps / float(np.median(dts)),                               # every region between its own fences (what r01 / r02 reported as value)
+            "value_spread": [min(blocks_per_s, args.steps / max(dts)), max(blocks_per_s, args.steps / min(dts))],     # fenced regions and the series
+            "region_ms": [round(1e3 * dts[i], 4) for i in sorted(set(np.linspace(0, len(dts) - 1, min(len(dts), 48)).astype(int).tolist()))],   # the fenced regions in order (evenly thinned to <= 48 entries)
+            "value_first5": args.steps / float(np.median(dts[:5])),                                  # fenced, a device just out of idle: the ramp (see the comment at `repeats`)
             "batches_timed": {"per_repeat": nbatch, "whole": full_batches, "ragged_blocks": args.steps - full_batches * T, "blocks_per_batch": T},
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{'cfg5' if args.cfg5 else {21: 'cfg2', 256: 'cfg3', 1024: 'cfg4'}.get(nsig, 'custom') if L == 8192 else 'custom'}: 1 ref + {nsig} signal rows x {L} int8 IQ samples per block, track cadence "
@@ -446,55 +474,59 @@ def main():
     elif rank == 0:
         result["cpu_baseline"] = None
 
-    # ---- extra, several GPUs: the same exchange through the C ABI (crsdr_exchange_*: grouped ncclSend / ncclRecv issued by
-    # libcrsdr.so itself, no Python collective in the loop).  `value` above was timed with torch.distributed's all-to-all;
-    # this leg re-times the same steps with the C transport.  It has never run on more than one GPU before the driver's
-    # node (RCCL refuses two ranks on one device), so it runs LAST and under a watchdog: if it does not finish, every rank
-    # reports what it has and leaves -- the figures above are not at risk.  CRSDR_BENCH_C_EXCHANGE=0 skips it.
-    if world > 1 and not rehearsal and os.environ.get("CRSDR_BENCH_C_EXCHANGE", "1") != "0":
+    # ---- the ONE result line goes out here, before anything that has not run on real links yet ----
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+
+    # ---- opt-in extra, several GPUs (CRSDR_BENCH_C_EXCHANGE=1): the same exchange through the C ABI (crsdr_exchange_*:
+    # grouped ncclSend / ncclRecv issued by libcrsdr.so itself, no Python collective in the loop), re-timing the same
+    # series.  The N > 1 RCCL wiring of this leg has never run on more than one GPU (RCCL refuses two ranks on one device;
+    # what is covered: the schedule for 1 .. 8 simulated ranks, the transport with one rank), so it is OFF by default, runs
+    # after the result line has been printed, reports on stderr, and a hang is a FAILURE: the watchdog exits non-zero.
+    if world > 1 and not rehearsal and os.environ.get("CRSDR_BENCH_C_EXCHANGE", "0") == "1":
         import threading
 
         def bail():
-            if rank == 0:
-                result["c_exchange"] = {"status": "timeout: the C-ABI RCCL leg did not finish within 90 s; figures above are from the torch.distributed transport"}
-                print(json.dumps(result), flush=True)
-            os._exit(0)
+            print(json.dumps({"c_exchange": {"status": "timeout: the C-ABI RCCL leg did not finish within 90 s", "rank": rank}}), file=sys.stderr, flush=True)
+            os._exit(3)                              # a hung collective is a finding, not an ok run
 
         wd = threading.Timer(90.0, bail)
         wd.daemon = True
         wd.start()
+        c_res, c_fail = None, False
         try:
             ids = [b.exchange_unique_id() if rank == 0 else None]
             dist.broadcast_object_list(ids, src=0)
             xchg["c"] = b.Exchange(ids[0], world, rank, local_rank)
             run_steps(max(args.warmup, 2 * T))
             fence()
-            dts_c = [timed(args.steps) for _ in range(repeats)]
-            dt_c = float(np.median(dts_c))
+            dt_c, dt_c_ev, _ = series(args.steps, repeats)
             torch.cuda.synchronize()
             ok = True
-            nfull = args.steps // T
-            if nfull:
-                ib = nfull - 1
+            if gib["last_full"] is not None and gib["n"] - gib["last_full"] <= NSETS:
+                ib = gib["last_full"]
                 for j, t_ in enumerate(sharding.rooted_range(T, world, rank)):
                     sc = b.parse_scalars(scal[ib % NSETS][j * sstride: (j + 1) * sstride].cpu().numpy(), nrows)
                     ok &= bool(np.array_equal(sc["lag"][1:], params.d))
                     ok &= int(pk_view[ib % NSETS][j][:4].cpu().numpy().view(np.uint32)[0]) == ib * T + t_
             flag = torch.tensor([1 if ok else 0], device=dev, dtype=torch.int32)
             dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-            if rank == 0:
-                result["c_exchange"] = {"status": "ok", "blocks_per_s": args.steps / dt_c, "ms_per_step": 1e3 * dt_c / args.steps,
-                                        "assembled": bool(flag.item()), "transport": "crsdr_exchange_batch (staged): grouped ncclSend/ncclRecv + crsdr assembly, one side stream"}
-        except Exception as e:                       # a failure here must not take the measured figures with it
-            if rank == 0:
-                result["c_exchange"] = {"status": f"error: {e}"}
+            c_res = {"status": "ok", "blocks_per_s": args.steps * repeats / dt_c, "ms_per_step": 1e3 * dt_c / (args.steps * repeats),
+                     "assembled": bool(flag.item()), "transport": "crsdr_exchange_batch (staged): grouped ncclSend/ncclRecv + crsdr assembly, one side stream"}
+            c_fail = not bool(flag.item())
+        except Exception as e:
+            c_res, c_fail = {"status": f"error: {e}"}, True
         wd.cancel()
+        if rank == 0:
+            print(json.dumps({"c_exchange": c_res}), file=sys.stderr, flush=True)
         xc, xchg["c"] = xchg["c"], None
         if xc is not None:
             xc.close()
+        if c_fail:
+            plan.close()
+            dist.destroy_process_group()
+            sys.exit(4)
 
-    if rank == 0:
-        print(json.dumps(result))
     plan.close()
     if world > 1:
         dist.destroy_process_group()

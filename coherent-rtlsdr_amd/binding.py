@@ -465,7 +465,8 @@ class Plan:
     def set_frac_apply(self, enable=True, gain=1.0, frac_override=None):
         """crsdr_plan_set_frac_apply: fractional-delay correction of the matrix rows (long-block plans, digital mode)."""
         ov = None if frac_override is None else np.ascontiguousarray(frac_override, dtype=np.float32)
-        _check(lib().crsdr_plan_set_frac_apply(self._h, int(bool(enable)), C.c_float(gain), _p(ov, C.c_float)))
+        # enable: False / 0 off, True / 1 on, 2 on without the second work area (the pass repeats its first stage)
+        _check(lib().crsdr_plan_set_frac_apply(self._h, int(enable), C.c_float(gain), _p(ov, C.c_float)))
 
     def bind_slab_ex(self, device_ptr: int | None, slab_stride: int = 0, hdr_first: int = 0, hdr_count: int = 0, tail_offset: int = 0):
         """crsdr_plan_bind_slab_ex: slab output with the per-row {lag, mag, frac, phasor} tail behind the rows of every slot."""

@@ -279,7 +279,11 @@ static hipError_t launch_xcorr_lag14(hipStream_t s, const XcorrArgs &a, int row_
         auto kq = x14p::k_xcorr_lag14q;
         hipError_t eq = hipFuncSetAttribute((const void *)kq, hipFuncAttributeMaxDynamicSharedMemorySize, x14p::LDSQ_BYTES);
         if (eq != hipSuccess) return eq;
-        static const int qspin = [] { const char *e = getenv("CRSDR_K1_QSPIN"); return e ? atoi(e) : x14p::kQSpinLimit; }();   // polls per wait; tests force 0
+        // polls per wait; tests force 0 ("0@3": from the process's fourth two-row launch on, so that clean launches come first)
+        static const int qspin_env = [] { const char *e = getenv("CRSDR_K1_QSPIN"); return e ? atoi(e) : x14p::kQSpinLimit; }();
+        static const long qspin_from = [] { const char *e = getenv("CRSDR_K1_QSPIN"); const char *at = e ? strchr(e, '@') : nullptr; return at ? atol(at + 1) : 0L; }();
+        static long qlaunches = 0;
+        const int qspin = qlaunches++ >= qspin_from ? qspin_env : x14p::kQSpinLimit;
         if (before_q) { hipError_t eb = before_q(); if (eb != hipSuccess) return eb; }   // snapshot of the carried state (rollback on a wait that ran out)
         hipLaunchKernelGGL(kq, dim3((unsigned)std::max(1, std::min(cus, (items + 1) / 2))), dim3(2 * x14p::QG), x14p::LDSQ_BYTES, s, a, twA, twB, row_count,
                            waitflag, work, *work_base, qspin);
@@ -739,10 +743,18 @@ struct crsdr_plan {
     // carried state {lag, mag, frac}_state + phase_state[0..1] lives in ONE allocation (d_state) so that the first two-row
     // launch after a clean status check can snapshot it with one stream-ordered copy; a wait that ran out rolls the
     // plan back to that snapshot (check_fused_status) and keeps later launches on the packed kernel
-    uint8_t *d_state = nullptr, *d_state_snap = nullptr;
+    uint8_t *d_state = nullptr, *d_state_snap = nullptr;   // d_state_snap: kSnaps copies (the ring below)
     size_t state_bytes = 0;
-    bool snap_valid = false, q_disabled = false;
-    int snap_phase_cur = 0;
+    bool q_disabled = false;
+    // Ring of stream-ordered snapshots of the carried state, one per batch that used a two-row / two-line kernel (entry = the
+    // state BEFORE that batch).  A status word read clean behind batch k retires every snapshot older than the state before
+    // batch k + 1; a wait that ran out rolls back to the OLDEST unretired one.  When the ring is full no new snapshot is
+    // taken (the rollback then simply reaches further back).
+    static constexpr int kSnaps = 8;
+    struct Snap { unsigned long idx; int phase_cur; } snaps[kSnaps] = {};
+    int snap_head = 0, snap_cnt = 0;
+    unsigned long submit_idx = 0;          // batches submitted since create / reset / rollback
+    unsigned long copy_idx[4] = {0, 0, 0, 0};   // submit index of the batch each outstanding asynchronous fetch belongs to
     bool fused_k2 = true, fused_used = false;
     int phase_cur = 0;
     int last_nblocks = 0;
@@ -801,7 +813,7 @@ static int plan_init_state(crsdr_plan *p)
     p->chain_armed[0] = p->chain_armed[1] = (int)T;
     p->phase_cur = 0;
     p->last_nblocks = 0;
-    p->snap_valid = false;
+    p->snap_cnt = 0; p->snap_head = 0;
     return CRSDR_OK;
 }
 
@@ -902,7 +914,7 @@ static int plan_alloc(crsdr_plan *p)
         const size_t n8 = (n + 1) / 2 * 2;                   // keeps the float2 arrays 8-byte aligned
         p->state_bytes = n8 * (3 * 4 + 2 * 8);
         HIP_TRY(hipMalloc((void **)&p->d_state, p->state_bytes));
-        HIP_TRY(hipMalloc((void **)&p->d_state_snap, p->state_bytes));
+        HIP_TRY(hipMalloc((void **)&p->d_state_snap, p->state_bytes * crsdr_plan::kSnaps));
         p->d_phase_state[0] = reinterpret_cast<float2 *>(p->d_state);
         p->d_phase_state[1] = p->d_phase_state[0] + n8;
         p->d_lag_state = reinterpret_cast<int32_t *>(p->d_phase_state[1] + n8);
@@ -1077,10 +1089,29 @@ extern "C" int crsdr_plan_bind_packet(crsdr_plan *p, void *device_packet, size_t
 extern "C" int crsdr_plan_set_frac_apply(crsdr_plan *p, int enable, float gain, const float *frac_override)
 {
     if (!p) return fail(CRSDR_EINVAL, "plan_set_frac_apply: NULL plan");
-    if (!enable) { p->frac_apply = false; return CRSDR_OK; }
+    if (enable < 0 || enable > 2) return fail(CRSDR_EINVAL, "plan_set_frac_apply: enable = %d (0 off, 1 on, 2 on without the second work area)", enable);
+    if (!enable) {
+        // off: the two buffers this call allocated go back (a second cf32 work area is 8 * blocksize bytes per owned row)
+        if (p->d_Z || p->d_rowspec) {
+            int rc = crsdr_plan_sync(p);
+            if (rc) return rc;
+            if (p->d_Z) (void)hipFree(p->d_Z);
+            if (p->d_rowspec) (void)hipFree(p->d_rowspec);
+            p->d_Z = nullptr; p->d_rowspec = nullptr;
+        }
+        p->frac_apply = false;
+        return CRSDR_OK;
+    }
     if (!p->longblock || p->mode != CRSDR_MODE_DIGITAL)
         return fail(CRSDR_EINVAL, "plan_set_frac_apply: needs a long-block plan (blocksize > 16384) in CRSDR_MODE_DIGITAL");
-    if (!(gain == gain)) return fail(CRSDR_EINVAL, "plan_set_frac_apply: gain is NaN");
+    // |D| is bounded: the response's phase k_s D / B is formed in fp32 (cis2pi), whose argument loses 6e-8 of its size per ulp --
+    // at |D| <= 64 samples the phase stays within 1e-5 rad.  A proper peak's parabolic estimate is |frac| <= 1/2, so D = gain * frac
+    // needs |gain| <= 128; caller-supplied delays beyond the bound belong in the integer lag (the resampler servo's business).
+    if (!(gain == gain) || std::fabs(gain) > 128.0f) return fail(CRSDR_EINVAL, "plan_set_frac_apply: gain must be finite, |gain| <= 128");
+    if (frac_override)
+        for (int r = 1; r < p->nrows; ++r)
+            if (!(std::fabs(frac_override[r]) <= 64.0f))
+                return fail(CRSDR_EINVAL, "plan_set_frac_apply: frac_override[%d] = %g (need |D| <= 64 samples; larger delays belong in the integer lag)", r, (double)frac_override[r]);
     HIP_TRY(hipSetDevice(p->device));
     if (frac_override) {
         int rc = crsdr_plan_sync(p);
@@ -1088,8 +1119,14 @@ extern "C" int crsdr_plan_set_frac_apply(crsdr_plan *p, int enable, float gain, 
         HIP_TRY(hipMemcpy(p->d_frac_override, frac_override, sizeof(float) * (size_t)p->nrows, hipMemcpyHostToDevice));
     }
     if (!p->d_rowspec) HIP_TRY(hipMalloc((void **)&p->d_rowspec, sizeof(float4) * 8192 * (size_t)p->row_count));
-    if (!p->d_Z && hipMalloc((void **)&p->d_Z, sizeof(float2) * (size_t)p->B * (size_t)p->row_count) != hipSuccess) {
-        p->d_Z = nullptr;                  // no room for a second work area: the apply pass repeats stage A instead
+    if (enable == 2 && p->d_Z) {           // memory-lean form asked for: give the second work area back
+        int rc = crsdr_plan_sync(p);
+        if (rc) return rc;
+        (void)hipFree(p->d_Z);
+        p->d_Z = nullptr;
+    }
+    if (enable == 1 && !p->d_Z && hipMalloc((void **)&p->d_Z, sizeof(float2) * (size_t)p->B * (size_t)p->row_count) != hipSuccess) {
+        p->d_Z = nullptr;                  // no room for a second work area: the apply pass repeats stage A instead (what enable = 2 asks for)
         (void)hipGetLastError();
     }
     p->frac_apply = true; p->frac_gain = gain; p->frac_override_on = frac_override != nullptr;
@@ -1104,6 +1141,28 @@ static int pack_tails(crsdr_plan *p, hipStream_t S, int nblocks, const int32_t *
                        p->row_begin, p->row_count, p->nrows, o_lag, o_mag, o_frac, p->d_phasor);
     HIP_TRY(hipGetLastError());
     return CRSDR_OK;
+}
+
+// Snapshot of the carried state before the batch now being submitted (at most one per batch; stream-ordered behind the previous
+// batch's kernels).  The entry only counts once the copy has been accepted by the runtime.
+static hipError_t take_snapshot(crsdr_plan *p, hipStream_t s)
+{
+    if (p->snap_cnt == crsdr_plan::kSnaps) return hipSuccess;                                   // full: the oldest stays the rollback point
+    if (p->snap_cnt && p->snaps[(p->snap_head + p->snap_cnt - 1) % crsdr_plan::kSnaps].idx == p->submit_idx) return hipSuccess;
+    const int pos = (p->snap_head + p->snap_cnt) % crsdr_plan::kSnaps;
+    const hipError_t e = hipMemcpyAsync(p->d_state_snap + (size_t)pos * p->state_bytes, p->d_state, p->state_bytes, hipMemcpyDeviceToDevice, s);
+    if (e != hipSuccess) return e;
+    p->snaps[pos].idx = p->submit_idx;
+    p->snaps[pos].phase_cur = p->phase_cur;
+    p->snap_cnt++;
+    return hipSuccess;
+}
+// The status word was read clean behind batch k: every batch <= k is good, so a snapshot is obsolete as soon as a newer one
+// that is still a state before some batch <= k + 1 exists; the last one goes too if nothing was submitted after batch k.
+static void retire_snapshots(crsdr_plan *p, unsigned long k)
+{
+    while (p->snap_cnt >= 2 && p->snaps[(p->snap_head + 1) % crsdr_plan::kSnaps].idx <= k + 1) { p->snap_head = (p->snap_head + 1) % crsdr_plan::kSnaps; p->snap_cnt--; }
+    if (p->snap_cnt == 1 && p->snaps[p->snap_head].idx <= k && p->submit_idx == k + 1) p->snap_cnt = 0;
 }
 
 extern "C" int crsdr_plan_submit_batch(crsdr_plan *p, const void *rows, int mem_kind, int nblocks, size_t block_stride,
@@ -1270,10 +1329,7 @@ extern "C" int crsdr_plan_submit_batch(crsdr_plan *p, const void *rows, int mem_
             const bool useq = longq && (kv == 'a' || kv == 'q') && !p->q_disabled && (long)n1 * cnt >= 1024;
             float2 *Zc = kept_fwd ? p->d_Z + (size_t)r0 * (size_t)p->B : Yc;
             if (useq) {
-                if (!p->snap_valid) {                      // same rollback protocol as the two-row K1 (check_fused_status)
-                    p->snap_valid = true; p->snap_phase_cur = p->phase_cur;
-                    HIP_TRY(hipMemcpyAsync(p->d_state_snap, p->d_state, p->state_bytes, hipMemcpyDeviceToDevice, S));
-                }
+                HIP_TRY(take_snapshot(p, S));              // same rollback protocol as the two-row K1 (check_fused_status)
                 HIP_TRY(launch_long_rows_q(S, n1, cnt, Yc, p->d_twA, p->d_twB, p->d_refspec[slot], reinterpret_cast<int *>(p->d_sync + 2), p->d_sync + 3, &p->q_work_base,
                                            nullptr, Zc != Yc ? Zc : nullptr));
                 p->k1_used = true;
@@ -1322,14 +1378,9 @@ extern "C" int crsdr_plan_submit_batch(crsdr_plan *p, const void *rows, int mem_
         if (pe1) HIP_TRY(hipEventRecord(pe1[0], KS));
         if (p->log2n == 14) {
             bool q = false;
-            // the first two-row launch since the last clean status check snapshots the carried state (one 28 B/row copy,
-            // ordered after the previous batch's kernels on this stream): what a wait that ran out is rolled back to
-            auto snapshot = [p, KS]() -> hipError_t {
-                if (p->snap_valid) return hipSuccess;
-                p->snap_valid = true;
-                p->snap_phase_cur = p->phase_cur;
-                return hipMemcpyAsync(p->d_state_snap, p->d_state, p->state_bytes, hipMemcpyDeviceToDevice, KS);
-            };
+            // every two-row launch snapshots the carried state first (one 28 B/row copy, ordered after the previous batch's
+            // kernels on this stream) while the ring has room: what a wait that ran out is rolled back to
+            auto snapshot = [p, KS]() -> hipError_t { return take_snapshot(p, KS); };
             // (with K1 on its own stream the phase kernel of the previous batch may still be writing the state: packed kernel there)
             HIP_TRY(launch_xcorr_lag14(KS, xa, p->row_count, p->d_twA, p->d_twB, reinterpret_cast<int *>(p->d_sync + 2), &q, p->d_sync + 3, &p->q_work_base,
                                        !p->q_disabled && !use_x, snapshot));
@@ -1381,6 +1432,7 @@ extern "C" int crsdr_plan_submit_batch(crsdr_plan *p, const void *rows, int mem_
         p->last_nblocks = nblocks;
         if (p->prof_slots) { if (p->prof_mask & (1u << 31)) HIP_TRY(hipEventRecord(p->ev_stop, S)); p->prof_count++; }
         p->submitted = true;
+        p->submit_idx++;
         return CRSDR_OK;
     }
     if (aa.refnoise) {
@@ -1427,10 +1479,7 @@ extern "C" int crsdr_plan_submit_batch(crsdr_plan *p, const void *rows, int mem_
                 if (longq2 && (kv2 == 'a' || kv2 == 'q') && !p->q_disabled && (long)n1 * cnt >= 1024) {
                     hipLaunchKernelGGL(x14p::k_ramp_rowspec, dim3(8192 / 256, cnt), dim3(256), 0, S, p->d_rowspec + (size_t)r0 * 8192, ra);
                     HIP_TRY(hipGetLastError());
-                    if (!p->snap_valid) {                  // (the same rollback protocol as the correlation pass)
-                        p->snap_valid = true; p->snap_phase_cur = p->phase_cur;
-                        HIP_TRY(hipMemcpyAsync(p->d_state_snap, p->d_state, p->state_bytes, hipMemcpyDeviceToDevice, S));
-                    }
+                    HIP_TRY(take_snapshot(p, S));          // (the same rollback protocol as the correlation pass)
                     HIP_TRY(launch_long_rows_q(S, n1, cnt, Yc, p->d_twA, p->d_twB, reinterpret_cast<float2 *>(p->d_rowspec + (size_t)r0 * 8192),
                                                reinterpret_cast<int *>(p->d_sync + 2), p->d_sync + 3, &p->q_work_base, &ra));
                     p->k1_used = true;
@@ -1449,6 +1498,7 @@ extern "C" int crsdr_plan_submit_batch(crsdr_plan *p, const void *rows, int mem_
     p->last_nblocks = nblocks;
     if (p->prof_slots) { if (p->prof_mask & (1u << 31)) HIP_TRY(hipEventRecord(p->ev_stop, S)); p->prof_count++; }
     p->submitted = true;
+    p->submit_idx++;
     return CRSDR_OK;
 }
 
@@ -1475,18 +1525,23 @@ static int check_fused_status(crsdr_plan *p)
             (void)hipStreamSynchronize(p->stream); (void)hipStreamSynchronize(p->aux); (void)hipStreamSynchronize(p->xs); (void)hipStreamSynchronize(p->cs);
             (void)hipMemset(p->d_sync, 0, 64);                    // flags and the work counter (its count is off after a failed launch)
             p->q_work_base = 0;
-            if (p->snap_valid) {
-                (void)hipMemcpy(p->d_state, p->d_state_snap, p->state_bytes, hipMemcpyDeviceToDevice);
-                p->phase_cur = p->snap_phase_cur;
+            unsigned long lost = 0;
+            if (p->snap_cnt) {
+                const crsdr_plan::Snap &sn = p->snaps[p->snap_head];      // the OLDEST unretired snapshot: the state before batch sn.idx
+                (void)hipMemcpy(p->d_state, p->d_state_snap + (size_t)p->snap_head * p->state_bytes, p->state_bytes, hipMemcpyDeviceToDevice);
+                p->phase_cur = sn.phase_cur;
+                lost = p->submit_idx - sn.idx;
+                p->submit_idx = sn.idx;
             }
             (void)hipMemset(p->d_corr, 0xFF, sizeof(long long) * 4 * (size_t)p->nrows * (size_t)p->max_batch);
             p->chain_armed[0] = p->chain_armed[1] = p->max_batch;
-            p->snap_valid = false; p->k1_used = false; p->q_disabled = true; p->submitted = false;
-            return fail(CRSDR_EHIP, "xcorr: %d workgroup(s) of the two-row kernel ran out of a bounded wait; the batches submitted since the last "
-                                    "successful sync / fetch were rolled back (carried lag and phase state restored) -- resubmit them; this plan now "
-                                    "uses the packed kernel (CRSDR_K1_VARIANT=packed selects it from the start)", w);
+            p->snap_cnt = 0; p->snap_head = 0; p->k1_used = false; p->q_disabled = true; p->submitted = false;
+            p->copy_pending = false; p->copy_head = p->copy_tail;       // outstanding asynchronous fetches delivered untrusted data: dropped
+            return fail(CRSDR_EHIP, "xcorr: %d workgroup(s) of the two-row kernel ran out of a bounded wait; the last %lu submitted batch(es) -- everything "
+                                    "since the last batch whose status was read clean -- were rolled back (carried lag and phase state restored): resubmit "
+                                    "them; this plan now uses the packed kernel (CRSDR_K1_VARIANT=packed selects it from the start)", w, lost);
         }
-        p->snap_valid = false; p->k1_used = false;               // clean: the next two-row launch takes a fresh snapshot
+        p->snap_cnt = 0; p->snap_head = 0; p->k1_used = false;      // clean and the streams are drained: the next two-row launch takes a fresh snapshot
     }
     static const bool dbg = [] { const char *e = getenv("CRSDR_K2_DEBUG"); return e && atoi(e) != 0; }();
     if (!p->fused_used || !dbg) return CRSDR_OK;
@@ -1544,6 +1599,7 @@ extern "C" int crsdr_plan_fetch_batch_async(crsdr_plan *p, int32_t *lag, float *
     // the next batch's upload included -- and serialise the two directions of the link: measured 25 + 25 instead of 45 GB/s)
     HIP_TRY(hipMemcpyAsync(&p->h_k1flag[p->copy_tail % 4], p->d_sync + 2, sizeof(int), hipMemcpyDeviceToHost, p->cs));
     HIP_TRY(hipEventRecord(p->ev_copydone[p->copy_tail % 4], p->cs));
+    p->copy_idx[p->copy_tail % 4] = p->submit_idx - 1;                     // the batch these copies (and this status word) sit behind
     p->copy_tail++;
     p->copy_pending = true;
     return CRSDR_OK;
@@ -1556,8 +1612,10 @@ extern "C" int crsdr_plan_fetch_wait(crsdr_plan *p)
     if (p->copy_head == p->copy_tail) return fail(CRSDR_ESTATE, "plan_fetch_wait: no asynchronous fetch outstanding");
     HIP_TRY(hipEventSynchronize(p->ev_copydone[p->copy_head % 4]));      // the OLDEST outstanding fetch: later ones keep flying
     const int w = p->h_k1flag[p->copy_head % 4];                          // copied behind that batch's kernels: final for it
+    const unsigned long k = p->copy_idx[p->copy_head % 4];
     p->copy_head++;
-    if (w) return crsdr_plan_sync(p);                                      // drains everything, rolls back, reports
+    if (w) return crsdr_plan_sync(p);                                      // drains everything, rolls back to the oldest unretired snapshot, reports
+    retire_snapshots(p, k);                                                // batches <= k are good: the rollback point moves up behind them
     return CRSDR_OK;
 }
 

@@ -225,7 +225,10 @@ extern "C" int crsdr_exchange_unique_id(void *id)
 {
     if (!id) return fail(CRSDR_EINVAL, "exchange_unique_id: NULL");
     { int rc_ = require_device(); if (rc_) return rc_; }
-    if (!g_rccl.load()) return fail(CRSDR_ENODEV, "exchange: librccl.so.1 not found (%s)", dlerror() ? dlerror() : "symbols missing");
+    if (!g_rccl.load()) {
+        const char *why = dlerror();           // read once: a second call returns NULL
+        return fail(CRSDR_ENODEV, "exchange: librccl.so.1 not found (%s)", why ? why : "symbols missing");
+    }
     xid u;
     RCCL_TRY(g_rccl.GetUniqueId(&u));
     std::memcpy(id, u.internal, CRSDR_EXCHANGE_ID_BYTES);
@@ -271,6 +274,18 @@ extern "C" int crsdr_exchange_batch(crsdr_exchange *x, int mode, const void *dev
     { int rc = xgeo(nrows, blocksize, x->nranks, &g); if (rc) return rc; }
     if (((uintptr_t)device_packets + g.matrix_off) % 4 || packet_stride % 4 || (uintptr_t)device_send % 16 || (device_recv && (uintptr_t)device_recv % 16))
         return fail(CRSDR_EINVAL, "exchange_batch: send / recv 16-byte aligned, matrix start and packet stride 4-byte aligned");
+    {
+        // the same stride checks as crsdr_assemble_slots: a short stride would let the assembly kernel -- or, in place, ncclRecv itself --
+        // write one block's rows / scalars over its neighbour's
+        int f0 = 0, c0 = 0;
+        xrooted(nblocks, x->nranks, x->rank, &f0, &c0);
+        const size_t body_off = g.matrix_off + (size_t)blocksize;
+        if (c0 > 1 && packet_stride < body_off + (size_t)(nrows - 1) * (size_t)blocksize)
+            return fail(CRSDR_EINVAL, "exchange_batch: packet_stride %zu is smaller than one packet (%zu bytes) and this rank assembles %d blocks", packet_stride,
+                        body_off + (size_t)(nrows - 1) * (size_t)blocksize, c0);
+        if (device_scalars && ((uintptr_t)device_scalars % 4 || scalars_stride % 4 || (c0 > 1 && scalars_stride < 20 * (size_t)nrows)))
+            return fail(CRSDR_EINVAL, "exchange_batch: device_scalars / scalars_stride 4-byte aligned, scalars_stride >= 20 * nrows");
+    }
     HIP_TRY(hipSetDevice(x->device));
     hipStream_t s = (hipStream_t)hip_stream;
     const int bpr = (nblocks + x->nranks - 1) / x->nranks;
@@ -279,7 +294,7 @@ extern "C" int crsdr_exchange_batch(crsdr_exchange *x, int mode, const void *dev
     if (mode == CRSDR_XCHG_INPLACE) {
         const size_t need = (size_t)x->nranks * (size_t)bpr * g.tail_slot;
         if (x->tail_cap < need) {                              // grows on the first batch (and when the geometry changes), never per batch after that
-            HIP_TRY(hipStreamSynchronize(s));
+            HIP_TRY(hipDeviceSynchronize());                    // earlier batches may have used other streams: nothing may still read the old staging
             if (x->tail_stage) (void)hipFree(x->tail_stage);
             x->tail_stage = nullptr; x->tail_cap = 0;
             HIP_TRY(hipMalloc((void **)&x->tail_stage, need));

@@ -1,5 +1,7 @@
 // ccoherent.cc -- see ccoherent.h.
 #include "ccoherent.h"
+#include <algorithm>
+#include <chrono>
 #include <cstdio>
 #include <cstring>
 
@@ -47,7 +49,11 @@ bool ccoherent::enable_batching(int T)
 {
     if (!plan || T < 1 || T > batch) return false;
     if (brows[0]) return true;
-    bstride = crsdr_plan_packet_stride(plan);
+    // host packets sit a whole reference-length message apart -- (16 + 4N) + 2 N blocksize by default (src/cpacketizer.cc:91-96) --
+    // and the memory starts out zero, so that a block's packet is published where it landed, zero tail included, without a copy
+    const size_t moff = crsdr_plan_matrix_offset(plan);
+    const size_t msg = cpacketize::refpadding ? moff + 2 * (size_t)nrows * (size_t)blocksize : packet_bytes;
+    bstride = (std::max(msg, packet_bytes) + 255) / 256 * 256;
     const size_t n = (size_t)nrows, Tz = (size_t)batch;
     for (int i = 0; i < 2; ++i) {
         if (crsdr_host_alloc((void **)&brows[i], Tz * n * (size_t)blocksize) != CRSDR_OK ||
@@ -59,32 +65,50 @@ bool ccoherent::enable_batching(int T)
             std::fprintf(stderr, "ccoherent: %s\n", crsdr_last_error());
             return false;
         }
+        std::memset(bpackets[i], 0, Tz * bstride);
+        breadcnt[i].assign(Tz * n, 0);
+        bmask[i].assign(n, 0);
     }
     return true;
 }
 
-bool ccoherent::fill_batch(int slot, int nblocks)
+bool ccoherent::fill_batch(int slot, int nblocks, const std::function<void(int)> &before_block)
 {
-    // the gather of step() (src/ccoherent.cc:250-283), nblocks times into one page-locked slot
+    if (!brows[0] || nblocks < 1 || nblocks > batch) return false;
+    std::fill(bmask[slot].begin(), bmask[slot].end(), (uint8_t)0);
     for (int t = 0; t < nblocks; ++t) {
+        if (before_block) before_block(t);
         int8_t *dst = brows[slot] + (size_t)t * nrows * blocksize;
-        std::memcpy(dst, refdev->read(), blocksize);
+        uint32_t *rc = breadcnt[slot].data() + (size_t)t * nrows;
+        std::memcpy(dst, refdev->read(), blocksize);                          // src/ccoherent.cc:250
+        if (do_exit) return false;                                            // woken by shutdown, not by data: the partial batch is dropped
+        rc[0] = refdev->get_readcntbuf();                                     // :253 -- the reference row's own counter
         refdev->consume();
         int c = 1;
-        for (auto *d : *devices) {
+        for (auto *d : *devices) {                                            // :262-283
             std::memcpy(dst + (size_t)c * blocksize, d->read(), blocksize);
-            d->consume();
+            rc[c] = d->get_readcntbuf();                                      // :278 -- what clients detect dropped blocks by (README.md:42)
+            if (d->is_lagrequested()) bmask[slot][c] = 1;                     // :266 -- a request made during the batch is served for the whole batch
+            d->consume();                                                     // :281
             ++c;
         }
     }
+    bool any = false;
+    for (int c = 1; c < nrows; ++c) any |= bmask[slot][c] != 0;
+    bflags[slot] = refnoise->isenabled() ? CRSDR_REFNOISE_ENABLED : 0;        // :271
+    if (refdev->is_streaming_raw()) bflags[slot] |= CRSDR_OFFSET_BINARY;      // ring holds raw uint8: XOR fused into the loads
+    if (!any) { bflags[slot] |= CRSDR_NO_LAG; locked_steps += (uint32_t)nblocks; }   // :284 -- nobody asked: "locked" cadence
+    bfilled[slot] = true;
     return true;
 }
 
 bool ccoherent::submit_batch(int slot, int nblocks, uint32_t flags)
 {
     if (!plan || !brows[0] || nblocks < 1 || nblocks > batch) return false;
+    const bool f = bfilled[slot];
     // H2D of this batch shares the link with the D2H of the previous one (crsdr_plan_fetch_batch_async); its kernels queue behind both
-    if (crsdr_plan_submit_batch(plan, brows[slot], CRSDR_MEM_HOST, nblocks, 0, nullptr, nullptr, seq, flags) != CRSDR_OK ||
+    if (crsdr_plan_submit_batch(plan, brows[slot], CRSDR_MEM_HOST, nblocks, 0, f ? breadcnt[slot].data() : nullptr, f ? bmask[slot].data() : nullptr, seq,
+                                flags | (f ? bflags[slot] : 0u)) != CRSDR_OK ||
         crsdr_plan_fetch_batch_async(plan, blag[slot], bmag[slot], bfrac[slot], bphasor[slot], bpackets[slot], bstride) != CRSDR_OK) {
         std::fprintf(stderr, "ccoherent: %s\n", crsdr_last_error());
         return false;
@@ -99,13 +123,21 @@ bool ccoherent::collect_batch(int slot)
     if (!plan || bcount[slot] < 1) return false;
     if (crsdr_plan_fetch_wait(plan) != CRSDR_OK) { std::fprintf(stderr, "ccoherent: %s\n", crsdr_last_error()); return false; }
     // (fetch_wait waits for the oldest outstanding fetch only: the batch submitted after this one keeps flying)
-    const int t = bcount[slot] - 1;                            // what get_lagp() / get_phasecorrect() show afterwards: the last block
-    int c = 1;
-    for (auto *d : *devices) {
-        d->set_lag((float)batch_lag(slot, t)[c], bmag[slot][(size_t)t * nrows + c]);          // src/ccoherent.cc:232-233
-        d->set_phasecorrect(std::complex<float>(batch_phasor(slot, t)[2 * c], batch_phasor(slot, t)[2 * c + 1]));
-        ++c;
+    const bool f = bfilled[slot];
+    const size_t msg_bytes = cpacketize::packetlength((uint32_t)nrows, (uint32_t)blocksize);
+    for (int t = 0; t < bcount[slot]; ++t) {                  // block by block, in order: what the per-block loop would have done
+        const int32_t *lg = batch_lag(slot, t);
+        const float *mg = bmag[slot] + (size_t)t * nrows, *ph = batch_phasor(slot, t);
+        int c = 1;
+        for (auto *d : *devices) {
+            if (!f || bmask[slot][c]) d->set_lag((float)lg[c], mg[c]);                                   // src/ccoherent.cc:232-233
+            d->set_phasecorrect(std::complex<float>(ph[2 * c], ph[2 * c + 1]));
+            ++c;
+        }
+        if (f && bpublish)                                     // :288 -- the plan assembled hdr0 + readcnt + matrix; the zero tail is in place
+            { cpacketize::publish(bpackets[slot] + (size_t)t * bstride, msg_bytes, reinterpret_cast<const std::complex<float> *>(ph), (size_t)nrows); ++published; }
     }
+    bfilled[slot] = false;
     return true;
 }
 
@@ -172,6 +204,21 @@ void ccoherent::threadf(ccoherent *ctx)
     while (!ctx->do_exit)
         if (!ctx->step()) break;
 }
+void ccoherent::threadf_batched(ccoherent *ctx, int T, int delay_us)
+{
+    if (!ctx->enable_batching(T)) return;
+    int b = 0;
+    bool pending = false;
+    while (!ctx->do_exit) {
+        if (!ctx->fill_batch(b & 1, T) || !ctx->submit_batch(b & 1, T, 0)) break;     // upload of batch b beside the download of batch b - 1
+        if (pending && !ctx->collect_batch((b - 1) & 1)) { pending = false; break; }
+        pending = true;
+        ++b;
+        if (delay_us > 0) std::this_thread::sleep_for(std::chrono::microseconds(delay_us));
+    }
+    if (pending) ctx->collect_batch((b - 1) & 1);
+}
 void ccoherent::start() { thread = std::thread(&ccoherent::threadf, this); }
+void ccoherent::start_batched(int T, int delay_us) { thread = std::thread(&ccoherent::threadf_batched, this, T, delay_us); }
 void ccoherent::request_exit() { do_exit = true; }
 void ccoherent::join() { thread.join(); }

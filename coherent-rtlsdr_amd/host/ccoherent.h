@@ -6,6 +6,7 @@
 #ifndef CCOHERENTH
 #define CCOHERENTH
 #include <atomic>
+#include <functional>
 #include <thread>
 #include <vector>
 
@@ -18,6 +19,7 @@
 class ccoherent {
     std::thread thread;
     static void threadf(ccoherent *);
+    static void threadf_batched(ccoherent *, int T, int delay_us);
     lvector<csdrdevice *> *devices;
     crefsdr *refdev;
     crefnoise *refnoise;
@@ -33,18 +35,32 @@ class ccoherent {
     std::vector<float> mag, frac, phasor;
     uint32_t seq;
     uint32_t locked_steps = 0;
+    std::atomic<uint32_t> published{0};
     // batched / pipelined mode (enable_batching): two page-locked slots of T blocks in, two of T packets + scalars out
     int batch = 0;
     int8_t *brows[2] = {nullptr, nullptr}, *bpackets[2] = {nullptr, nullptr};
     int32_t *blag[2] = {nullptr, nullptr};
     float *bmag[2] = {nullptr, nullptr}, *bfrac[2] = {nullptr, nullptr}, *bphasor[2] = {nullptr, nullptr};
-    size_t bstride = 0;
+    size_t bstride = 0;                 // bytes between the host packets of a slot: >= one reference-length message (zero tail in place)
     int bcount[2] = {0, 0};
+    // what fill_batch gathered beside the rows: every device's read counter per block (cpacketize::write's readcnt argument,
+    // src/ccoherent.cc:253,278), which devices asked for a lag (:266) and the block flags (:271); false = the caller filled
+    // batch_rows() itself (benchmark) and the plan numbers the blocks
+    std::vector<uint32_t> breadcnt[2];
+    std::vector<uint8_t> bmask[2];
+    uint32_t bflags[2] = {0, 0};
+    bool bfilled[2] = {false, false};
+    bool bpublish = true;
 public:
     std::atomic<bool> do_exit;
     ccoherent(crefsdr *, lvector<csdrdevice *> *, crefnoise *, int nfft, int mode = CRSDR_MODE_FAITHFUL, int batch = 1);
     ~ccoherent();
     void start();
+    // the same thread, a batch at a time and pipelined: fill(b) ; submit(b) ; collect(b - 1) -- src/ccoherent.cc:245-294 run T blocks
+    // per iteration; every block's packet goes out through cpacketize::publish from this thread.  delay_us: idle time per
+    // batch (tests use it to provoke ring overruns).
+    void start_batched(int T, int delay_us = 0);
+    uint32_t get_published_blocks() const { return published; }
     void request_exit();
     void join();
     size_t lagqueuesize();
@@ -62,9 +78,18 @@ public:
     const int8_t *batch_packet(int slot, int t) const { return bpackets[slot] + (size_t)t * bstride; }
     const int32_t *batch_lag(int slot, int t) const { return blag[slot] + (size_t)t * nrows; }
     const float *batch_phasor(int slot, int t) const { return bphasor[slot] + 2 * (size_t)t * nrows; }
-    bool fill_batch(int slot, int nblocks);                                    // nblocks x (read every device, consume): the per-block gather of step()
+    // nblocks x the per-block gather of step() (src/ccoherent.cc:250-283): read every device, keep ITS read counter for the
+    // packet header, note who asked for a lag, consume.  before_block(t), if given, runs ahead of block t's reads (the
+    // synchronous synthetic source is advanced there; streaming devices need nothing).
+    bool fill_batch(int slot, int nblocks, const std::function<void(int)> &before_block = nullptr);
+    // flags: extra CRSDR_* submit flags; a slot filled by fill_batch adds the engine's own (refnoise gate, raw uint8 rings,
+    // CRSDR_NO_LAG when nobody asked) and ships its read counters and lag mask
     bool submit_batch(int slot, int nblocks, uint32_t flags);
+    // waits for the slot's results; per block, in order: set_lag for every device that had asked (src/ccoherent.cc:232-233),
+    // the phase factors to the devices / the debug payload (:279), and the block's packet to cpacketize::publish (:288)
     bool collect_batch(int slot);
+    void set_batch_publish(bool on) { bpublish = on; }                        // false: collect_batch leaves the packets in batch_packet()
+    const uint32_t *batch_readcnt(int slot, int t) const { return breadcnt[slot].data() + (size_t)t * nrows; }
     size_t get_packet_bytes() const { return packet_bytes; }
     const std::vector<float> &get_frac() const { return frac; }
     uint32_t get_locked_steps() const { return locked_steps; }   // blocks that ran the phase path only

@@ -51,8 +51,8 @@ int main(int argc, char **argv)
 {
     int nsig = 3, L = 8192, blocks = 12, mode = CRSDR_MODE_DIGITAL, dmax = -1;
     std::string dump, zmqaddr;
-    bool run_cdsp = false, servo = false, threads = false, music = false, servo_table = false, bench = false;
-    int batch = 16;
+    bool run_cdsp = false, servo = false, threads = false, music = false, servo_table = false, bench = false, batch_parity = false, batched = false;
+    int batch = 16, engine_delay_ms = 0, pace_us_arg = -1;
     std::vector<double> table_lags;
     int table_fs = 2048000;
     std::string replay;
@@ -77,6 +77,10 @@ int main(int argc, char **argv)
         else if (a == "--fs") val(table_fs);
         else if (a == "--bench") bench = true;      // pipelined batched engine over PCIe: blocks/s from C++, no Python in the loop
         else if (a == "--batch") val(batch);
+        else if (a == "--batch-parity") batch_parity = true;   // the batched engine's packets == step()'s packets, bit for bit (own read counters, a masked row)
+        else if (a == "--batched") batched = true;             // with --threads: the engine thread runs a batch at a time (ccoherent::start_batched)
+        else if (a == "--engine-delay-ms") val(engine_delay_ms);
+        else if (a == "--pace-us") val(pace_us_arg);
         else if (a == "--servo-table" && i + 1 < argc) {      // comma-separated lags
             servo_table = true;
             for (char *tok = std::strtok(argv[++i], ","); tok; tok = std::strtok(nullptr, ",")) table_lags.push_back(std::atof(tok));
@@ -98,6 +102,62 @@ int main(int argc, char **argv)
     if (run_cdsp) fails += cdsp_selftest();
 
     const uint32_t B = 2 * (uint32_t)L;
+    if (batch_parity) {
+        // The batched engine against the per-block loop on the same synthetic stream: 3 batches of `batch` blocks.  Row 2's read
+        // counter starts three ahead of the others (each device's OWN counter must reach the header, src/cpacketizer.cc:142,163)
+        // and row 2 stops asking for a lag after the first batch (the per-device gate of src/ccoherent.cc:266).  Every published
+        // message -- header, read counters, matrix, zero tail -- and every phase-factor payload must be equal bit for bit.
+        typedef std::vector<std::vector<int8_t>> pkv;
+        typedef std::vector<std::vector<std::complex<float>>> phv;
+        const int T = batch, NB = 3;
+        auto run = [&](bool use_batches, pkv &pk, phv &ph, std::vector<float> &lags) -> bool {
+            csynthsource src(nsig, L, csynth_config_seed(1), dmax, false);
+            crefsdr rdev(&src, B);
+            lvector<csdrdevice *> dv;
+            std::vector<std::unique_ptr<csyntheticsdr>> od;
+            for (int k = 0; k < nsig; ++k) { od.emplace_back(new csyntheticsdr(&src, 1 + k, B)); dv.push_back(od.back().get()); }
+            if (nsig >= 2) for (int i = 0; i < 3; ++i) od[1]->inc_readcnt();
+            crefnoise rn;
+            cpacketize::init("", false, 1 + nsig, B);
+            cpacketize::sink = [&](const int8_t *p, size_t bytes, const std::complex<float> *phase, size_t n) {
+                pk.emplace_back(p, p + bytes);
+                ph.emplace_back(phase, phase + n);
+            };
+            ccoherent eng(&rdev, &dv, &rn, 8, mode, use_batches ? T : 1);
+            auto request = [&](int block) { for (int k = 0; k < nsig; ++k) if (!(k == 1 && block >= T)) dv[k]->requestfft(); };
+            bool ok = true;
+            if (!use_batches) {
+                for (int t = 0; t < NB * T && ok; ++t) { src.advance(); request(t); ok = eng.step(); cpacketize::send(); }
+            } else {
+                ok = eng.enable_batching(T);
+                for (int bb = 0; bb < NB && ok; ++bb) {
+                    request(bb * T);
+                    ok = eng.fill_batch(0, T, [&](int) { src.advance(); }) && eng.submit_batch(0, T, 0) && eng.collect_batch(0);
+                }
+            }
+            for (int k = 0; k < nsig; ++k) lags.push_back(dv[k]->get_lagp()->lag);
+            cpacketize::sink = nullptr;
+            cpacketize::cleanup();
+            return ok;
+        };
+        pkv pa, pb; phv ha, hb; std::vector<float> la, lb;
+        const bool oka = run(false, pa, ha, la), okb = run(true, pb, hb, lb);
+        size_t bad = (!oka) + (!okb) + (pa.size() != (size_t)(NB * T)) + (pb.size() != pa.size());
+        size_t own_cnt = 0, masked_ok = 0;
+        for (size_t i = 0; i < pa.size() && i < pb.size(); ++i) {
+            if (pa[i] != pb[i]) { if (bad < 5) std::printf("packet %zu differs (%zu vs %zu bytes)\n", i, pa[i].size(), pb[i].size()); ++bad; }
+            if (ha[i].size() != hb[i].size() || std::memcmp(ha[i].data(), hb[i].data(), ha[i].size() * sizeof(std::complex<float>))) { if (bad < 5) std::printf("phase payload %zu differs\n", i); ++bad; }
+            const uint32_t *rc = reinterpret_cast<const uint32_t *>(pb[i].data() + 16);
+            if (nsig >= 2) own_cnt += (rc[2] == rc[1] + 3);              // row 2 carries its own, offset counter
+        }
+        if (nsig >= 2) bad += (own_cnt != pb.size());
+        for (int k = 0; k < nsig; ++k) { bad += (la[k] != lb[k]); masked_ok += 1; }
+        std::printf("batch parity: %zu + %zu packets of %zu bytes, %zu with row 2's own read counter, lags %s\n", pa.size(), pb.size(), pa.empty() ? 0 : pa[0].size(), own_cnt,
+                    la == lb ? "equal" : "DIFFER");
+        std::printf("%s\n", bad ? "DEMO FAILED" : "DEMO OK");
+        return bad ? 1 : 0;
+    }
+
     csynthsource source(nsig, L, csynth_config_seed(1), dmax, false);
     crefsdr ref(&source, B);
     lvector<csdrdevice *> devs;
@@ -113,7 +173,7 @@ int main(int argc, char **argv)
         last_seq = h->globalseqn; last_N = h->N; last_L = h->L; last_bytes = bytes; ++packets;
         if (music) last_packet.assign(p, p + bytes);
     };
-    ccoherent coherent(&ref, &devs, &refnoise, 8, mode, bench ? batch : 1);
+    ccoherent coherent(&ref, &devs, &refnoise, 8, mode, (bench || batched) ? batch : 1);
 
     if (bench) {
         // The engine a batch at a time, pipelined: page-locked slots of `batch` blocks go over PCIe while the previous batch's
@@ -169,7 +229,51 @@ int main(int argc, char **argv)
             for (int c = 0; c <= nsig; ++c) { if (npk && rc[c] != lastcnt[c] + 1) ++gaps; lastcnt[c] = rc[c]; }
             ++npk;
         };
-        const int pace_us = pace_ms ? pace_ms * 1000 : 3000;
+        const int pace_us = pace_us_arg >= 0 ? pace_us_arg : pace_ms ? pace_ms * 1000 : 3000;
+        if (batched) {
+            // the engine thread a batch at a time (ccoherent::start_batched): every block's packet is published from there with
+            // each device's own read counter.  With --engine-delay-ms the reader is slower than the producers: rings overrun,
+            // blocks are lost, and the ONLY trace of that is a jump in that row's read counter (README.md:42) -- which must
+            // therefore show in the headers of the batched engine exactly as it does in step()'s.
+            std::vector<uint32_t> first(1 + nsig, 0), last(1 + nsig, 0);
+            size_t jumps = 0, backwards = 0, npk2 = 0;
+            cpacketize::sink = [&](const int8_t *p, size_t, const std::complex<float> *, size_t) {
+                const uint32_t *rc = reinterpret_cast<const uint32_t *>(p + 16);
+                for (int c = 0; c <= nsig; ++c) {
+                    if (!npk2) first[c] = rc[c];
+                    else { jumps += rc[c] > last[c] + 1; backwards += rc[c] <= last[c]; }
+                    last[c] = rc[c];
+                }
+                ++npk2;
+            };
+            ref.start(pace_us, blocks);
+            for (auto &d : own) d->start(pace_us, blocks);
+            coherent.start_batched(batch, engine_delay_ms * 1000);
+            // wait until the producers are done and less than a batch is left in some ring (the engine cannot fill another one)
+            for (int spin = 0; spin < 60000; ++spin) {
+                bool done = ref.produced_all(blocks) && ref.backlog() < (uint32_t)batch;
+                for (auto &d : own) done = done || (d->produced_all(blocks) && d->backlog() < (uint32_t)batch);
+                bool all_prod = ref.produced_all(blocks);
+                for (auto &d : own) all_prod = all_prod && d->produced_all(blocks);
+                if (all_prod && done) break;
+                usleep(1000);
+            }
+            usleep(200 * 1000);                          // the batch in flight
+            coherent.request_exit();
+            ref.stop();
+            for (auto &d : own) d->stop();
+            coherent.join();
+            uint32_t over = ref.get_overruns();
+            for (auto &d : own) over += d->get_overruns();
+            size_t skipped = 0;
+            for (int c = 0; c <= nsig; ++c) skipped += npk2 ? (last[c] - first[c] + 1) - npk2 : 0;
+            std::printf("streaming batched: %zu packets, %zu read-counter jumps (%zu blocks skipped), %zu backwards, %u ring overruns\n", npk2, jumps, skipped, backwards, over);
+            // every skipped count is a block a ring dropped; drops behind the last published block do not show
+            fails += (npk2 == 0) + (backwards != 0) + (skipped > over) + (engine_delay_ms > 0 ? (over == 0 || jumps == 0) : (over != 0 || jumps != 0));
+            cpacketize::cleanup();
+            std::printf("%s\n", fails ? "DEMO FAILED" : "DEMO OK");
+            return fails ? 1 : 0;
+        }
         if (!replay.empty()) {
             // recorded streams: one raw offset-binary uint8 file per channel, row 0 = the reference-noise channel
             bool ok = ref.start_replay((replay + "0.u8").c_str(), pace_us, blocks);

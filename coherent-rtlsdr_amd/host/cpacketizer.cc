@@ -133,6 +133,18 @@ int cpacketize::send()
     return 0;
 }
 
+int cpacketize::publish(const int8_t *message, size_t bytes, const std::complex<float> *phase, size_t n)
+{
+    // src/cpacketizer.cc:125,127 for a packet that was assembled elsewhere (header included: its globalseqn is the engine's)
+    const int8_t *m = message;
+    if (noheader) m += 16 + 4 * n;                             // -R: the matrix alone; `bytes` (= packetlength) already excludes the header
+    if (g_sock) zq.send(g_sock, m, bytes, 0);
+    if (g_dbg && phase) zq.send(g_dbg, phase, n * sizeof(std::complex<float>), 0);
+    if (sink) sink(m, bytes, phase, n);
+    globalseqn++;
+    return 0;
+}
+
 int cpacketize::writedebug(uint32_t channeln, std::complex<float> p)
 {
     pcorrection[channeln] = p;                                 // src/cpacketizer.cc:131-134

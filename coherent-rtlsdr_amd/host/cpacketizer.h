@@ -49,6 +49,10 @@ public:
 
     // -- publish loop, main thread (src/main.cc:277-279; src/cpacketizer.cc:109-129)
     static int send();
+    // -- a message that is already assembled (the batched engine: the plan wrote hdr0 + readcnt + matrix, the zero tail is in
+    // place): `bytes` = packetlength(N, blocksize) starting at the header -- with noheader the matrix alone is sent --
+    // plus the N phase factors of the debug side channel.  Called from ONE thread; do not run the send() loop beside it.
+    static int publish(const int8_t *message, size_t bytes, const std::complex<float> *phase, size_t n);
 
 private:
     static void resize_buffers(uint32_t N, uint32_t L);

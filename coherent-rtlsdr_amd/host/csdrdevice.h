@@ -153,6 +153,8 @@ public:
     bool is_streaming_raw() const { return (bool)ring; } // rows are raw uint8 (offset binary) in streaming mode
     uint32_t get_overruns() const { return overruns; }
     // streaming mode: the producer has made `total` blocks and none is left in the ring (read() would block for ever)
+    bool produced_all(uint32_t total) { std::lock_guard<std::mutex> lock(mtx); return ring && get_readcnt() >= total; }
+    uint32_t backlog() { std::lock_guard<std::mutex> lock(mtx); return ring ? ring->backlog() : 0; }
     bool drained(uint32_t total) { std::lock_guard<std::mutex> lock(mtx); return ring && get_readcnt() >= total && ring->backlog() == 0; }
     int set_correction_f(float f) { correction = f; return 0; } // crtlsdr::set_correction_f src/crtlsdr.cc:167-170
     float get_correction_f() const { return correction; }

@@ -209,9 +209,14 @@ int crsdr_plan_fetch_block(crsdr_plan *plan, int block, int32_t *lag, float *mag
  * the frequency domain: X[f] * exp(+2 pi i f_s (lag_k + D_k) / B), f_s the signed bin index -- then rotated by the phasor
  * and quantised like cdsp::convto8bit; for D = 0 that is the digital mode's zero-filled integer shift.
  *   D_k = frac_override[k] if given (host [nrows], copied; entry 0 ignored), else gain * frac_k (this block's estimate).
+ *   Bounds: |gain| <= 128 and |frac_override[k]| <= 64 samples (CRSDR_EINVAL otherwise): the response's phase is formed in fp32 and
+ *   keeps 1e-5 rad up to there; a proper peak's estimate is |frac| <= 1/2.  Larger delays belong in the integer lag.
  * lag / mag / frac / phasor outputs are unchanged (the phase is still estimated on the integer-aligned row).
- * Enabling it allocates (once, here -- never on the per-block path) a second cf32 work area of 8 * blocksize bytes per owned row and
- * 128 KiB per owned row for the rows' response spectra; if the work area cannot be had the pass repeats its first stage instead. */
+ *   enable = 1: allocates (once, here -- never on the per-block path) a second cf32 work area of 8 * blocksize bytes per owned row,
+ *               so that the correction pass reuses the correlation pass's first stage, and 128 KiB per owned row for the rows'
+ *               response spectra; if the work area cannot be had the pass repeats its first stage instead (= enable 2);
+ *   enable = 2: the memory-lean form: no second work area, the pass repeats its first stage (same results, bit for bit);
+ *   enable = 0: off; both buffers are freed (after a sync). */
 int crsdr_plan_set_frac_apply(crsdr_plan *plan, int enable, float gain, const float *frac_override);
 
 /* Pipelined fetch of the LAST submitted batch into page-locked host memory (crsdr_host_alloc): the device-to-host copies

@@ -167,4 +167,45 @@ def test_frac_apply_argument_checks(b):
     faithful = b.Plan(3, 1 << 15, b.MODE_FAITHFUL)
     with pytest.raises(b.CrsdrError):
         faithful.set_frac_apply(True)                 # the faithful mode never shifts samples
-    short.close(); faithful.close()
+    longp = b.Plan(3, 1 << 15, b.MODE_DIGITAL)
+    with pytest.raises(b.CrsdrError):
+        longp.set_frac_apply(True, 1000.0)            # |gain| <= 128: D = gain * frac stays where the fp32 phase keeps 1e-5 rad
+    with pytest.raises(b.CrsdrError):
+        longp.set_frac_apply(True, 1.0, np.array([0.0, 0.5, 200.0], dtype=np.float32))   # |D| <= 64 samples: the rest belongs in the lag
+    with pytest.raises(b.CrsdrError):
+        longp.set_frac_apply(True, 1.0, np.array([0.0, np.nan, 0.0], dtype=np.float32))
+    with pytest.raises(b.CrsdrError):
+        longp.set_frac_apply(3)                       # enable: 0, 1 or 2
+    longp.set_frac_apply(True, 1.0, np.array([7.0, 64.0, -64.0], dtype=np.float32))      # entry 0 (the reference row) is not looked at
+    short.close(); faithful.close(); longp.close()
+
+
+def test_frac_apply_without_second_work_area_is_bit_identical(b, synth):
+    # crsdr_plan_set_frac_apply(enable = 1) keeps the correlation pass's first stage in a second cf32 work area (cfg5: 352 MB) so
+    # that the correction pass does not repeat it; when that buffer cannot be had -- or is not wanted: enable = 2 -- the pass runs
+    # its first stage again.  Same arithmetic on the same inputs: every output must agree bit for bit.  cfg5's shape, because
+    # only launches of >= 1024 lines take the two-line stage-B kernel that writes out of place.  Switching the correction off
+    # gives the buffers back.
+    import torch
+    nsig, L = 21, 1 << 20
+    params = synth.RowParams(nsig, L, 4242, dmax=L // 8)
+    D = np.linspace(-0.5, 0.5, nsig + 1).astype(np.float32)
+    rows = [synth.make_block(nsig, L, 4242, t, params=params)[0] for t in range(2)]
+    torch.cuda.synchronize()
+    outs, held = {}, {}
+    for enable in (1, 2):
+        plan = b.Plan(nsig + 1, 2 * L, b.MODE_DIGITAL)
+        free0, _ = torch.cuda.mem_get_info()
+        plan.set_frac_apply(enable, 1.0, D)
+        free1, _ = torch.cuda.mem_get_info()
+        held[enable] = free0 - free1
+        outs[enable] = [plan.block(r, seq=t) for t, r in enumerate(rows)]
+        plan.set_frac_apply(False)
+        free2, _ = torch.cuda.mem_get_info()
+        assert free2 >= free0 - (8 << 20), (enable, free0, free2)            # the buffers set_frac_apply allocated are freed again
+        plan.close()
+    assert held[1] - held[2] >= 8 * 2 * L * nsig - (16 << 20), held          # enable = 1 really held the second work area, enable = 2 did not
+    for t in range(2):
+        for key in ("lag", "mag", "frac", "phasor", "packet"):
+            assert np.array_equal(outs[1][t][key].view(np.uint8), outs[2][t][key].view(np.uint8)), (t, key)
+        assert np.array_equal(outs[1][t]["lag"][1:], params.d)

@@ -688,6 +688,88 @@ def test_two_row_kernel_reports_a_wait_that_ran_out(tmp_path):
     assert np.array_equal(outs["runout"]["lag"][-1, 1:], outs["runout"]["d"])
 
 
+def test_pipelined_fetch_rolls_back_to_the_last_clean_batch(tmp_path):
+    # The host loop of the batched engine never calls sync / fetch: submit, fetch_batch_async, fetch_wait only.  A bounded wait
+    # of the two-row kernel that runs out at batch 3 -- after three CLEAN two-row batches (CRSDR_K1_QSPIN=0@3: spin budget zero
+    # from the process's fourth two-row launch on) -- must roll the plan back to the state before batch 3, not to the state
+    # before batch 0 (r02: the only snapshot was taken at the first two-row launch and a clean fetch_wait never renewed it), and
+    # say how many batches to resubmit.  Resubmitting that one batch, then a locked batch that shifts by the carried lags,
+    # gives bit for bit what a plan on the packed kernel gives.
+    import subprocess, sys, textwrap
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = textwrap.dedent('''
+        import importlib, sys, numpy as np
+        sys.path.insert(0, %r)
+        pkg = importlib.import_module("coherent-rtlsdr_amd")
+        b, synth = pkg.binding, pkg.synth
+        nsig, L, T, NB = 300, 8192, 12, 5                 # 3600 rows per batch (>= 12 per CU): "auto" takes the two-row kernel
+        nrows, B = nsig + 1, 2 * L
+        params = synth.RowParams(nsig, L, 77, dmax=1000)
+        blocks = np.stack([synth.make_block(nsig, L, 77, t, params=params)[0] for t in range(4 * 4)])      # 16 distinct blocks, cycled
+        batch = lambda i: np.stack([blocks[(i * T + t) %% 16] for t in range(T)])
+        plan = b.Plan(nrows, B, b.MODE_DIGITAL, max_batch=T)
+        ps = plan.packet_stride
+        rows_pin = [b.PinnedArray((T, nrows, B), np.int8) for _ in range(2)]
+        out = [dict(lag=b.PinnedArray((T, nrows), np.int32), mag=b.PinnedArray((T, nrows), np.float32), frac=b.PinnedArray((T, nrows), np.float32),
+                    phasor=b.PinnedArray((T, nrows, 2), np.float32), packets=b.PinnedArray((T * ps,), np.int8)) for _ in range(2)]
+        res = {}
+        def submit(i, flags=b.REFNOISE_ENABLED):
+            s = i & 1
+            rows_pin[s].array[:] = batch(i)
+            plan.submit(rows_pin[s].array, seq=i * T, flags=flags)
+            o = out[s]
+            plan.fetch_batch_async(o["lag"].array, o["mag"].array, o["frac"].array, o["phasor"].array, o["packets"].array, ps)
+        def collect(i):
+            plan.fetch_wait()
+            o = out[i & 1]
+            res[i] = {k: v.array.copy() for k, v in o.items()}
+        errors = []
+        submit(0)
+        i = 1
+        while i < NB:
+            fl = b.REFNOISE_ENABLED | (b.NO_LAG if i == NB - 1 else 0)     # the last batch is locked: it shifts by the carried lags
+            submit(i, fl)
+            try:
+                collect(i - 1)
+            except b.CrsdrError as e:
+                errors.append(str(e))
+                # batches i - 1 and i (submitted behind the failed one) are gone: resubmit from the first lost one
+                lost = int(str(e).split("the last ")[1].split(" ")[0])
+                first = i + 1 - lost
+                print("ERROR at collect", i - 1, "lost", lost, "first", first)
+                submit(first, b.REFNOISE_ENABLED)
+                i = first + 1
+                continue
+            i += 1
+        try:
+            collect(NB - 1)
+        except b.CrsdrError as e:
+            errors.append(str(e))
+            lost = int(str(e).split("the last ")[1].split(" ")[0])
+            print("ERROR at final collect lost", lost)
+            for k in range(NB - lost, NB):
+                submit(k, b.REFNOISE_ENABLED | (b.NO_LAG if k == NB - 1 else 0))
+                collect(k)
+        print("NERR", len(errors))
+        for e in errors: print(e)
+        np.savez(sys.argv[1], **{f"{k}{i}": v for i, r in res.items() for k, v in r.items()}, d=params.d)
+    ''') % root
+    outs = {}
+    for name, env, nerr in (("runout", {"CRSDR_K1_VARIANT": "auto", "CRSDR_K1_QSPIN": "0@3"}, 1), ("packed", {"CRSDR_K1_VARIANT": "packed"}, 0)):
+        out = tmp_path / f"{name}.npz"
+        r = subprocess.run([sys.executable, "-c", code, str(out)], env=dict(os.environ, **env), capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stdout + r.stderr
+        assert f"NERR {nerr}" in r.stdout, r.stdout + r.stderr
+        if nerr:
+            # batch 3 failed; batch 4 had been submitted behind it: two batches to resubmit, never the clean batches 0 .. 2
+            assert "rolled back" in r.stdout and "lost 2 first 3" in r.stdout, r.stdout
+        outs[name] = np.load(out)
+    assert set(outs["packed"].files) == set(outs["runout"].files)
+    for key in outs["packed"].files:
+        assert np.array_equal(outs["packed"][key].view(np.uint8), outs["runout"][key].view(np.uint8)), key
+    assert np.array_equal(outs["runout"]["lag4"][-1, 1:], outs["runout"]["d"])
+
+
 def test_plan_lifecycle_does_not_leak_device_memory(b, synth):
     # create / submit / destroy in a loop (all three kernel families: generic, 16384, long-block): device memory
     # in use returns to where it started (the plan owns every device allocation, src/ccoherent.cc:100-110)

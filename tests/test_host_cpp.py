@@ -183,3 +183,37 @@ def test_replay_of_recorded_streams(host_build, synth, tmp_path):
     lags = [int(line.split("lag")[1]) for line in r.stdout.splitlines() if line.startswith("row ") and "lag" in line]
     assert lags == [int(d) for d in params.d]
     assert f"streaming: {nblocks} packets, 0 readcnt gaps" in r.stdout
+
+
+@pytest.mark.gpu
+def test_batched_engine_packets_equal_the_per_block_loop(host_build):
+    # src/ccoherent.cc:245-294 a batch at a time: fill_batch keeps every device's OWN read counter for the header
+    # (src/cpacketizer.cc:142,163) and the per-device lag gate (src/ccoherent.cc:266); collect_batch calls set_lag for every
+    # block and publishes every block's packet.  Against ccoherent::step() on the same synthetic stream, three batches, with
+    # one device's counter offset by 3 and one device that stops asking for a lag after the first batch: every message
+    # (header, read counters, matrix, zero tail) and every phase-factor payload must be equal bit for bit.
+    for extra in (["--nsig", "5", "--batch", "4"], ["--nsig", "3", "--batch", "6", "--faithful"]):
+        r = subprocess.run([os.path.join(host_build, "coherent_demo"), "--batch-parity"] + extra, capture_output=True, text=True, timeout=300)
+        print(r.stdout, r.stderr)
+        assert r.returncode == 0 and "DEMO OK" in r.stdout, r.stdout + r.stderr
+        n = 3 * int(extra[3])
+        assert f"{n} + {n} packets" in r.stdout and f"{n} with row 2's own read counter" in r.stdout and "lags equal" in r.stdout
+
+
+@pytest.mark.gpu
+def test_batched_streaming_engine_shows_ring_overruns_in_the_header_readcnts(host_build):
+    # producer threads -> rings -> the engine thread a batch at a time -> cpacketize::publish.  A reader that is slower than
+    # the producers loses blocks in the rings (README.md:42), and the only trace of a lost block is a jump in that row's read
+    # counter -- r02's batched engine numbered the rows seq + t and hid it.  Clean run first: no overruns, no jumps.
+    exe = os.path.join(host_build, "coherent_demo")
+    clean = subprocess.run([exe, "--threads", "--batched", "--nsig", "3", "--blocks", "48", "--batch", "4", "--pace-us", "4000"],
+                           capture_output=True, text=True, timeout=300)
+    print(clean.stdout, clean.stderr)
+    assert clean.returncode == 0 and "DEMO OK" in clean.stdout and " 0 read-counter jumps" in clean.stdout and " 0 ring overruns" in clean.stdout, clean.stdout + clean.stderr
+    slow = subprocess.run([exe, "--threads", "--batched", "--nsig", "3", "--blocks", "240", "--batch", "4", "--pace-us", "300", "--engine-delay-ms", "40"],
+                          capture_output=True, text=True, timeout=300)
+    print(slow.stdout, slow.stderr)
+    assert slow.returncode == 0 and "DEMO OK" in slow.stdout, slow.stdout + slow.stderr
+    import re
+    m = re.search(r"(\d+) packets, (\d+) read-counter jumps \((\d+) blocks skipped\), (\d+) backwards, (\d+) ring overruns", slow.stdout)
+    assert m and int(m.group(2)) > 0 and 0 < int(m.group(3)) <= int(m.group(5)) and int(m.group(4)) == 0
