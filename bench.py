@@ -119,7 +119,15 @@ def main():
     block_bytes = nrows * B
 
     plan = b.Plan(nrows, B, mode, device=local_rank, row_begin=slab.row_begin, row_count=slab.row_count, max_batch=T)
-    stream = torch.cuda.current_stream()
+    # An explicit compute stream, made torch's current stream: the plan launches on it, torch.distributed's collectives order
+    # themselves behind it, and the events below are recorded on it.  (torch's DEFAULT stream is the null stream, handle 0 --
+    # which crsdr_plan_set_stream reads as "the plan's own stream": r01 / r02 ran the plan on its own non-blocking stream while
+    # every wait_event / collective ordering of the N > 1 path went to the null stream, i.e. the all-to-all was not ordered behind
+    # the submit it ships.  One GPU never noticed: its fences are device-wide.)
+    stream = torch.cuda.Stream(device=dev)
+    torch.cuda.set_stream(stream)
+    assert stream.cuda_stream != 0
+    torch.cuda.synchronize()                            # the input blocks above were filled on the null stream
     plan.set_stream(stream.cuda_stream)
     if args.cfg5 and args.frac_apply:
         plan.set_frac_apply(True, 1.0, None)

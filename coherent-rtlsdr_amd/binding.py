@@ -33,6 +33,7 @@ ABI_SYMBOLS = [
     "crsdr_device_info", "crsdr_host_alloc", "crsdr_host_free",
     "crsdr_plan_bind_slab_ex", "crsdr_exchange_geometry", "crsdr_exchange_rooted_blocks", "crsdr_assemble_slots",
     "crsdr_plan_set_frac_apply", "crsdr_plan_fetch_batch_async", "crsdr_plan_fetch_wait", "crsdr_exchange_unique_id", "crsdr_exchange_create", "crsdr_exchange_destroy", "crsdr_exchange_batch", "crsdr_exchange_schedule",
+    "crsdr_exchange_bind_plan", "crsdr_exchange_submit_batch", "crsdr_exchange_fetch_rooted",
 ]
 XCHG_STAGED, XCHG_INPLACE = 0, 1
 EXCHANGE_ID_BYTES = 128

@@ -151,6 +151,17 @@ struct crsdr_exchange {
     bool selfloop = false;
     int8_t *tail_stage = nullptr;
     size_t tail_cap = 0;
+    // a bound plan (crsdr_exchange_bind_plan): two ring-buffered sets of device buffers, the exchange on its own stream
+    crsdr_plan *plan = nullptr;
+    int xmode = 0, bpr = 0;
+    XGeo geo;
+    size_t pstride = 0, pk_off[2] = {0, 0};
+    int8_t *d_send[2] = {nullptr, nullptr}, *d_recv[2] = {nullptr, nullptr}, *d_packets[2] = {nullptr, nullptr}, *d_scal[2] = {nullptr, nullptr};
+    hipStream_t xs = nullptr, cs = nullptr;
+    hipEvent_t ev_sub = nullptr, ev_done[2] = {nullptr, nullptr};
+    bool done_valid[2] = {false, false};
+    struct { int nblocks, first, count; unsigned long idx; } out[2] = {};
+    unsigned long head = 0, tail = 0;          // batches fetched / submitted
 };
 
 extern "C" int crsdr_plan_bind_slab_ex(crsdr_plan *p, void *device_slab, size_t slab_stride, int hdr_first, int hdr_count, size_t tail_offset)
@@ -258,8 +269,20 @@ extern "C" int crsdr_exchange_destroy(crsdr_exchange *x)
 {
     if (!x) return fail(CRSDR_EINVAL, "exchange_destroy: NULL");
     (void)hipSetDevice(x->device);
+    if (x->plan) {
+        (void)hipDeviceSynchronize();
+        (void)crsdr_plan_bind_slab(x->plan, nullptr, 0, 0, 0);
+        (void)crsdr_plan_bind_packet(x->plan, nullptr, 0);
+    }
     if (x->comm) (void)g_rccl.CommDestroy(x->comm);
     if (x->tail_stage) (void)hipFree(x->tail_stage);
+    for (int k = 0; k < 2; ++k) {
+        for (int8_t *b : {x->d_send[k], x->d_recv[k], x->d_packets[k], x->d_scal[k]}) if (b) (void)hipFree(b);
+        if (x->ev_done[k]) (void)hipEventDestroy(x->ev_done[k]);
+    }
+    if (x->ev_sub) (void)hipEventDestroy(x->ev_sub);
+    if (x->xs) (void)hipStreamDestroy(x->xs);
+    if (x->cs) (void)hipStreamDestroy(x->cs);
     delete x;
     return CRSDR_OK;
 }
@@ -329,4 +352,107 @@ extern "C" int crsdr_exchange_batch(crsdr_exchange *x, int mode, const void *dev
     if (x->selfloop) return CRSDR_OK;
     return launch_assemble(s, (int8_t *)device_packets, packet_stride, (int8_t *)device_scalars, scalars_stride, nrows, g.per, blocksize, self_slots, 1, myc, g.slot,
                            g.rows_bytes, tails, x->rank, -1, -1, nullptr, 0);
+}
+
+
+// ---- a sharded plan and its exchange as one engine (include/crsdr.h) -------------------------------------------------------------
+extern "C" int crsdr_exchange_bind_plan(crsdr_exchange *x, crsdr_plan *plan, int mode)
+{
+    if (!x || !plan) return fail(CRSDR_EINVAL, "exchange_bind_plan: NULL exchange or plan");
+    if (mode != CRSDR_XCHG_STAGED && mode != CRSDR_XCHG_INPLACE) return fail(CRSDR_EINVAL, "exchange_bind_plan: mode = %d", mode);
+    if (x->plan) return fail(CRSDR_ESTATE, "exchange_bind_plan: a plan is already bound");
+    XGeo g;
+    { int rc = xgeo(plan->nrows, plan->B, x->nranks, &g); if (rc) return rc; }
+    if (plan->device != x->device || plan->row_count != g.per || plan->row_begin != 1 + x->rank * g.per)
+        return fail(CRSDR_EINVAL, "exchange_bind_plan: the plan must live on device %d and own rank %d's slab: rows [%d, %d) of %d (it owns [%d, %d) on device %d)", x->device,
+                    x->rank, 1 + x->rank * g.per, 1 + (x->rank + 1) * g.per, plan->nrows, plan->row_begin, plan->row_begin + plan->row_count, plan->device);
+    HIP_TRY(hipSetDevice(x->device));
+    x->geo = g; x->xmode = mode;
+    x->bpr = (plan->max_batch + x->nranks - 1) / x->nranks;
+    x->pstride = (plan->packet_bytes + 255) / 256 * 256;
+    HIP_TRY(hipStreamCreateWithFlags(&x->xs, hipStreamNonBlocking));
+    HIP_TRY(hipStreamCreateWithFlags(&x->cs, hipStreamNonBlocking));
+    HIP_TRY(hipEventCreateWithFlags(&x->ev_sub, hipEventDisableTiming));
+    for (int k = 0; k < 2; ++k) {
+        HIP_TRY(hipEventCreateWithFlags(&x->ev_done[k], hipEventDisableTiming));
+        HIP_TRY(hipMalloc((void **)&x->d_send[k], (size_t)plan->max_batch * g.slot));
+        HIP_TRY(hipMalloc((void **)&x->d_recv[k], (size_t)x->nranks * (size_t)x->bpr * g.slot));
+        HIP_TRY(hipMalloc((void **)&x->d_packets[k], (size_t)x->bpr * x->pstride + 256));
+        HIP_TRY(hipMalloc((void **)&x->d_scal[k], (size_t)x->bpr * g.scalars));
+        HIP_TRY(hipMemset(x->d_packets[k], 0, (size_t)x->bpr * x->pstride + 256));
+        HIP_TRY(hipMemset(x->d_scal[k], 0, (size_t)x->bpr * g.scalars));
+        x->pk_off[k] = (256 - ((uintptr_t)x->d_packets[k] + g.matrix_off) % 256) % 256;      // the matrix of every packet 256-byte aligned
+    }
+    HIP_TRY(hipDeviceSynchronize());
+    x->plan = plan;
+    return CRSDR_OK;
+}
+
+extern "C" int crsdr_exchange_submit_batch(crsdr_exchange *x, const void *rows, int mem_kind, int nblocks, size_t block_stride, const uint32_t *readcnt,
+                                           const uint8_t *lag_mask, uint32_t seq, uint32_t flags)
+{
+    if (!x || !x->plan) return fail(CRSDR_ESTATE, "exchange_submit_batch: no plan bound (crsdr_exchange_bind_plan)");
+    if (x->tail - x->head >= 2) return fail(CRSDR_ESTATE, "exchange_submit_batch: two batches outstanding, call crsdr_exchange_fetch_rooted first");
+    crsdr_plan *p = x->plan;
+    if (nblocks < 1 || nblocks > p->max_batch) return fail(CRSDR_EINVAL, "exchange_submit_batch: nblocks = %d (plan max_batch = %d)", nblocks, p->max_batch);
+    HIP_TRY(hipSetDevice(x->device));
+    const int k = (int)(x->tail & 1);
+    hipStream_t S = p->stream;
+    if (x->done_valid[k]) HIP_TRY(hipStreamWaitEvent(S, x->ev_done[k], 0));      // set k is free again: its exchange and assembly are complete
+    int f = 0, c = 0;
+    xrooted(nblocks, x->nranks, x->rank, &f, &c);
+    int8_t *pk = x->d_packets[k] + x->pk_off[k];
+    int rc;
+    if ((rc = crsdr_plan_bind_packet(p, pk, x->pstride))) return rc;
+    if ((rc = crsdr_plan_bind_slab_ex(p, x->d_send[k], x->geo.slot, f, c, x->geo.rows_bytes))) return rc;
+    if ((rc = crsdr_plan_submit_batch(p, rows, mem_kind, nblocks, block_stride, readcnt, lag_mask, seq, flags))) return rc;
+    HIP_TRY(hipEventRecord(x->ev_sub, S));
+    HIP_TRY(hipStreamWaitEvent(x->xs, x->ev_sub, 0));
+    // the exchange and the assembly run on the side stream: the plan's stream is free for the next batch (into the other set)
+    if ((rc = crsdr_exchange_batch(x, x->xmode, x->d_send[k], x->d_recv[k], nblocks, pk, x->pstride, x->d_scal[k], x->geo.scalars, p->nrows, p->B, x->xs))) return rc;
+    HIP_TRY(hipEventRecord(x->ev_done[k], x->xs));
+    x->done_valid[k] = true;
+    x->out[k].nblocks = nblocks; x->out[k].first = f; x->out[k].count = c; x->out[k].idx = p->submit_idx - 1;
+    x->tail++;
+    return CRSDR_OK;
+}
+
+extern "C" int crsdr_exchange_fetch_rooted(crsdr_exchange *x, int8_t *packets, size_t host_packet_stride, void *scalars, size_t host_scalars_stride,
+                                           void *own_tails, size_t host_tails_stride, int *first, int *count, int *nblocks)
+{
+    if (!x || !x->plan) return fail(CRSDR_ESTATE, "exchange_fetch_rooted: no plan bound");
+    if (x->head == x->tail) return fail(CRSDR_ESTATE, "exchange_fetch_rooted: nothing submitted");
+    crsdr_plan *p = x->plan;
+    const int k = (int)(x->head & 1), c = x->out[k].count;
+    if (packets && c > 1 && host_packet_stride < p->packet_bytes) return fail(CRSDR_EINVAL, "exchange_fetch_rooted: host_packet_stride smaller than a packet");
+    if (scalars && c > 1 && host_scalars_stride < 20 * (size_t)p->nrows) return fail(CRSDR_EINVAL, "exchange_fetch_rooted: host_scalars_stride smaller than 20 * nrows");
+    if (own_tails && x->out[k].nblocks > 1 && host_tails_stride < x->geo.tail_bytes) return fail(CRSDR_EINVAL, "exchange_fetch_rooted: host_tails_stride smaller than 20 * rows per rank");
+    HIP_TRY(hipSetDevice(x->device));
+    HIP_TRY(hipStreamWaitEvent(x->cs, x->ev_done[k], 0));
+    const int8_t *pk = x->d_packets[k] + x->pk_off[k];
+    if (own_tails)       // {lag, mag, frac, phasor} of this rank's own rows for EVERY block of the batch: the tails of its send slots
+        HIP_TRY(hipMemcpy2DAsync(own_tails, host_tails_stride, x->d_send[k] + x->geo.rows_bytes, x->geo.slot, x->geo.tail_bytes, (size_t)x->out[k].nblocks,
+                                 hipMemcpyDeviceToHost, x->cs));
+    for (int j = 0; j < c; ++j) {
+        if (packets) HIP_TRY(hipMemcpyAsync(packets + (size_t)j * host_packet_stride, pk + (size_t)j * x->pstride, p->packet_bytes, hipMemcpyDeviceToHost, x->cs));
+        if (scalars) HIP_TRY(hipMemcpyAsync((int8_t *)scalars + (size_t)j * host_scalars_stride, x->d_scal[k] + (size_t)j * x->geo.scalars, 20 * (size_t)p->nrows,
+                                            hipMemcpyDeviceToHost, x->cs));
+    }
+    // the two-row kernel's status word behind this batch's kernels (as crsdr_plan_fetch_wait reads it)
+    HIP_TRY(hipMemcpyAsync(&p->h_k1flag[x->head % 4], p->d_sync + 2, sizeof(int), hipMemcpyDeviceToHost, x->cs));
+    HIP_TRY(hipStreamSynchronize(x->cs));
+    const int w = p->h_k1flag[x->head % 4];
+    const unsigned long idx = x->out[k].idx;
+    if (first) *first = x->out[k].first;
+    if (count) *count = c;
+    if (nblocks) *nblocks = x->out[k].nblocks;
+    x->head++;
+    if (w) {
+        x->head = x->tail;                                   // whatever else was outstanding went through the same garbage lags
+        x->done_valid[0] = x->done_valid[1] = false;
+        (void)hipDeviceSynchronize();
+        return crsdr_plan_sync(p);                            // rolls the plan back and reports
+    }
+    retire_snapshots(p, idx);
+    return CRSDR_OK;
 }

@@ -5,19 +5,38 @@
 #include <cstdio>
 #include <cstring>
 
-ccoherent::ccoherent(crefsdr *refdev_, lvector<csdrdevice *> *devvec_, crefnoise *refnoise_, int nfft_, int mode_, int batch_)
+ccoherent::ccoherent(crefsdr *refdev_, lvector<csdrdevice *> *devvec_, crefnoise *refnoise_, int nfft_, int mode_, int batch_, const ccoherent_shard *shard)
     : devices(devvec_), refdev(refdev_), refnoise(refnoise_), nfft(nfft_), mode(mode_), plan(nullptr), rows(nullptr), packet(nullptr), packet_bytes(0), seq(0), do_exit(false)
 {
     blocksize = (int)refdev->get_blocksize();                 // src/ccoherent.cc:43
     nrows = 1 + (int)devices->size();
     crsdr_plan_desc d;
     std::memset(&d, 0, sizeof(d));
-    d.nrows = nrows; d.blocksize = blocksize; d.mode = mode; d.device = 0;
+    d.nrows = nrows; d.blocksize = blocksize; d.mode = mode; d.device = shard ? shard->device : 0;
     d.max_batch = batch_ > 1 ? batch_ : 1;
     batch = d.max_batch;
+    per = nrows - 1;
+    if (shard && shard->id) {                                  // one process per GPU: this one owns rank's slab of the signal rows
+        ranks = shard->ranks; rank = shard->rank;
+        if (ranks < 1 || rank < 0 || rank >= ranks || (nrows - 1) % ranks) {
+            std::fprintf(stderr, "ccoherent: %d signal rows do not split over %d ranks (rank %d)\n", nrows - 1, ranks, rank);
+            return;
+        }
+        per = (nrows - 1) / ranks;
+        row_begin = 1 + rank * per;
+        d.row_begin = row_begin; d.row_count = per;
+    }
     if (crsdr_plan_create(&plan, &d) != CRSDR_OK) {
         // same convention as the reference's backend-init failure (src/ccoherent.cc:54-61): print and continue
         std::fprintf(stderr, "ccoherent: %s\n", crsdr_last_error());
+        plan = nullptr;
+    }
+    if (plan && shard && shard->id &&
+        (crsdr_exchange_create(&xchg, shard->id, ranks, rank, shard->device) != CRSDR_OK || crsdr_exchange_bind_plan(xchg, plan, shard->xmode) != CRSDR_OK)) {
+        std::fprintf(stderr, "ccoherent: %s\n", crsdr_last_error());
+        if (xchg) crsdr_exchange_destroy(xchg);
+        xchg = nullptr;
+        crsdr_plan_destroy(plan);
         plan = nullptr;
     }
     readcnt.resize(nrows); mask.resize(nrows); lag.resize(nrows); mag.resize(nrows); frac.resize(nrows);
@@ -36,7 +55,9 @@ ccoherent::ccoherent(crefsdr *refdev_, lvector<csdrdevice *> *devvec_, crefnoise
 ccoherent::~ccoherent()
 {
     if (thread.joinable()) thread.join();
+    if (xchg) crsdr_exchange_destroy(xchg);
     if (plan) crsdr_plan_destroy(plan);
+    for (int i = 0; i < 2; ++i) { crsdr_host_free(bscal[i]); crsdr_host_free(btails[i]); }
     crsdr_host_free(rows);
     crsdr_host_free(packet);
     for (int i = 0; i < 2; ++i) {
@@ -68,6 +89,14 @@ bool ccoherent::enable_batching(int T)
         std::memset(bpackets[i], 0, Tz * bstride);
         breadcnt[i].assign(Tz * n, 0);
         bmask[i].assign(n, 0);
+        if (xchg) {
+            sstride = (20 * n + 15) / 16 * 16;
+            tstride = (20 * (size_t)per + 15) / 16 * 16;
+            if (crsdr_host_alloc((void **)&bscal[i], Tz * sstride) != CRSDR_OK || crsdr_host_alloc((void **)&btails[i], Tz * tstride) != CRSDR_OK) {
+                std::fprintf(stderr, "ccoherent: %s\n", crsdr_last_error());
+                return false;
+            }
+        }
     }
     return true;
 }
@@ -106,6 +135,17 @@ bool ccoherent::submit_batch(int slot, int nblocks, uint32_t flags)
 {
     if (!plan || !brows[0] || nblocks < 1 || nblocks > batch) return false;
     const bool f = bfilled[slot];
+    if (xchg) {
+        // sharded: the plan writes this rank's rows + tails into the exchange's send slots, the exchange assembles on the rotating root
+        if (crsdr_exchange_submit_batch(xchg, brows[slot], CRSDR_MEM_HOST, nblocks, 0, f ? breadcnt[slot].data() : nullptr, f ? bmask[slot].data() : nullptr, seq,
+                                        flags | (f ? bflags[slot] : 0u)) != CRSDR_OK) {
+            std::fprintf(stderr, "ccoherent: %s\n", crsdr_last_error());
+            return false;
+        }
+        seq += (uint32_t)nblocks;
+        bcount[slot] = nblocks;
+        return true;
+    }
     // H2D of this batch shares the link with the D2H of the previous one (crsdr_plan_fetch_batch_async); its kernels queue behind both
     if (crsdr_plan_submit_batch(plan, brows[slot], CRSDR_MEM_HOST, nblocks, 0, f ? breadcnt[slot].data() : nullptr, f ? bmask[slot].data() : nullptr, seq,
                                 flags | (f ? bflags[slot] : 0u)) != CRSDR_OK ||
@@ -121,6 +161,35 @@ bool ccoherent::submit_batch(int slot, int nblocks, uint32_t flags)
 bool ccoherent::collect_batch(int slot)
 {
     if (!plan || bcount[slot] < 1) return false;
+    if (xchg) {
+        int first = 0, count = 0, nb = 0;
+        if (crsdr_exchange_fetch_rooted(xchg, bpackets[slot], bstride, bscal[slot], sstride, btails[slot], tstride, &first, &count, &nb) != CRSDR_OK) {
+            std::fprintf(stderr, "ccoherent: %s\n", crsdr_last_error());
+            return false;
+        }
+        brooted_first[slot] = first; brooted_count[slot] = count;
+        const bool f = bfilled[slot];
+        // every block: the lags of THIS rank's rows to the devices this process reads (src/ccoherent.cc:232-233) ...
+        for (int t = 0; t < nb; ++t) {
+            const int8_t *tl = btails[slot] + (size_t)t * tstride;
+            const int32_t *lg = reinterpret_cast<const int32_t *>(tl);
+            const float *mg = reinterpret_cast<const float *>(tl + 4 * (size_t)per), *ph = reinterpret_cast<const float *>(tl + 12 * (size_t)per);
+            for (int i = 0; i < per; ++i) {
+                csdrdevice *d = (*devices)[(size_t)(row_begin - 1 + i)];
+                if (!f || bmask[slot][row_begin + i]) d->set_lag((float)lg[i], mg[i]);
+                d->set_phasecorrect(std::complex<float>(ph[2 * i], ph[2 * i + 1]));
+            }
+        }
+        // ... and the blocks assembled HERE go out whole (:288): all N rows, all N phase factors
+        const size_t msg_bytes = cpacketize::packetlength((uint32_t)nrows, (uint32_t)blocksize);
+        for (int j = 0; j < count && f && bpublish; ++j) {
+            const std::complex<float> *ph = reinterpret_cast<const std::complex<float> *>(bscal[slot] + (size_t)j * sstride + 12 * (size_t)nrows);
+            cpacketize::publish(bpackets[slot] + (size_t)j * bstride, msg_bytes, ph, (size_t)nrows);
+            ++published;
+        }
+        bfilled[slot] = false;
+        return true;
+    }
     if (crsdr_plan_fetch_wait(plan) != CRSDR_OK) { std::fprintf(stderr, "ccoherent: %s\n", crsdr_last_error()); return false; }
     // (fetch_wait waits for the oldest outstanding fetch only: the batch submitted after this one keeps flying)
     const bool f = bfilled[slot];

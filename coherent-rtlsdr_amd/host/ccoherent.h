@@ -16,6 +16,15 @@
 #include "crefnoise.h"
 #include "csdrdevice.h"
 
+// Rows split over the GPUs of a node, one process per GPU: rank r of `ranks` owns signal rows [1 + r * per, 1 + (r + 1) * per),
+// per = (N - 1) / ranks, on HIP device `device`; `id` = the CRSDR_EXCHANGE_ID_BYTES rank 0 got from crsdr_exchange_unique_id and handed to
+// the others (a file, a socket, MPI).  id == nullptr with ranks == 1: an ordinary unsharded engine on `device`.
+struct ccoherent_shard {
+    int ranks = 1, rank = 0, device = 0;
+    const void *id = nullptr;
+    int xmode = CRSDR_XCHG_STAGED;
+};
+
 class ccoherent {
     std::thread thread;
     static void threadf(ccoherent *);
@@ -51,9 +60,19 @@ class ccoherent {
     uint32_t bflags[2] = {0, 0};
     bool bfilled[2] = {false, false};
     bool bpublish = true;
+    // sharded engine (ccoherent_shard with an id): the plan owns this rank's slab, the exchange assembles on a rotating root
+    crsdr_exchange *xchg = nullptr;
+    int ranks = 1, rank = 0, per = 0, row_begin = 1;
+    int8_t *bscal[2] = {nullptr, nullptr}, *btails[2] = {nullptr, nullptr};    // page-locked: scalars blocks of the rooted blocks, own-row tails of every block
+    size_t sstride = 0, tstride = 0;
+    int brooted_first[2] = {0, 0}, brooted_count[2] = {0, 0};
 public:
     std::atomic<bool> do_exit;
-    ccoherent(crefsdr *, lvector<csdrdevice *> *, crefnoise *, int nfft, int mode = CRSDR_MODE_FAITHFUL, int batch = 1);
+    ccoherent(crefsdr *, lvector<csdrdevice *> *, crefnoise *, int nfft, int mode = CRSDR_MODE_FAITHFUL, int batch = 1, const ccoherent_shard *shard = nullptr);
+    bool ok() const { return plan != nullptr; }
+    bool sharded() const { return xchg != nullptr; }
+    int batch_rooted_first(int slot) const { return brooted_first[slot]; }     // sharded: the blocks of the slot's batch this rank assembled
+    int batch_rooted_count(int slot) const { return brooted_count[slot]; }
     ~ccoherent();
     void start();
     // the same thread, a batch at a time and pipelined: fill(b) ; submit(b) ; collect(b - 1) -- src/ccoherent.cc:245-294 run T blocks

@@ -53,6 +53,9 @@ int main(int argc, char **argv)
     std::string dump, zmqaddr;
     bool run_cdsp = false, servo = false, threads = false, music = false, servo_table = false, bench = false, batch_parity = false, batched = false;
     int batch = 16, engine_delay_ms = 0, pace_us_arg = -1;
+    bool engine_batches = false;
+    int ranks = 1, rank = 0, device = 0;
+    std::string idfile;
     std::vector<double> table_lags;
     int table_fs = 2048000;
     std::string replay;
@@ -81,6 +84,13 @@ int main(int argc, char **argv)
         else if (a == "--batched") batched = true;             // with --threads: the engine thread runs a batch at a time (ccoherent::start_batched)
         else if (a == "--engine-delay-ms") val(engine_delay_ms);
         else if (a == "--pace-us") val(pace_us_arg);
+        // one process per GPU: --engine-batches --ranks G --rank r --device d --id-file <path>; start the G processes
+        // yourself (a shell loop, mpirun, ...): rank 0 writes the exchange id to the file, the others wait for it
+        else if (a == "--engine-batches") engine_batches = true;
+        else if (a == "--ranks") val(ranks);
+        else if (a == "--rank") val(rank);
+        else if (a == "--device") val(device);
+        else if (a == "--id-file" && i + 1 < argc) idfile = argv[++i];
         else if (a == "--servo-table" && i + 1 < argc) {      // comma-separated lags
             servo_table = true;
             for (char *tok = std::strtok(argv[++i], ","); tok; tok = std::strtok(nullptr, ",")) table_lags.push_back(std::atof(tok));
@@ -156,6 +166,78 @@ int main(int argc, char **argv)
                     la == lb ? "equal" : "DIFFER");
         std::printf("%s\n", bad ? "DEMO FAILED" : "DEMO OK");
         return bad ? 1 : 0;
+    }
+
+    if (engine_batches) {
+        // The batched engine as a program: synchronous synthetic source -> fill_batch -> submit_batch -> collect_batch, pipelined over
+        // two slots, every block's packet published (sink: one digest line per packet).  With --id-file the signal rows are split over
+        // --ranks processes, one per GPU: each owns a slab, the exchange (RCCL under the C ABI) assembles every block on its rotating
+        // root, and each rank publishes the blocks it assembled -- the union over the ranks is the unsharded engine's output.
+        // (Every rank generates the whole synthetic matrix; only row 0 and its slab go to its GPU.)
+        unsigned char xid[CRSDR_EXCHANGE_ID_BYTES];
+        ccoherent_shard sh;
+        sh.ranks = ranks; sh.rank = rank; sh.device = device;
+        if (!idfile.empty()) {
+            if (rank == 0) {
+                if (crsdr_exchange_unique_id(xid) != CRSDR_OK) { std::printf("exchange id: %s\nDEMO FAILED\n", crsdr_last_error()); return 1; }
+                const std::string tmp = idfile + ".tmp";
+                FILE *f = std::fopen(tmp.c_str(), "wb");
+                if (!f || std::fwrite(xid, 1, sizeof(xid), f) != sizeof(xid)) { std::printf("cannot write %s\nDEMO FAILED\n", tmp.c_str()); return 1; }
+                std::fclose(f);
+                std::rename(tmp.c_str(), idfile.c_str());              // atomic: a reader never sees half an id
+            } else {
+                bool got = false;
+                for (int spin = 0; spin < 1200 && !got; ++spin) {      // up to 60 s for rank 0 to come up
+                    FILE *f = std::fopen(idfile.c_str(), "rb");
+                    if (f) { got = std::fread(xid, 1, sizeof(xid), f) == sizeof(xid); std::fclose(f); }
+                    if (!got) usleep(50 * 1000);
+                }
+                if (!got) { std::printf("rank %d: no exchange id in %s\nDEMO FAILED\n", rank, idfile.c_str()); return 1; }
+            }
+            sh.id = xid;
+        }
+        csynthsource src(nsig, L, csynth_config_seed(1), dmax, false);
+        crefsdr rdev(&src, B);
+        lvector<csdrdevice *> dv;
+        std::vector<std::unique_ptr<csyntheticsdr>> od;
+        for (int k = 0; k < nsig; ++k) { od.emplace_back(new csyntheticsdr(&src, 1 + k, B)); dv.push_back(od.back().get()); }
+        crefnoise rn;
+        cpacketize::init(zmqaddr, false, 1 + nsig, B);
+        size_t npk = 0, badhdr = 0;
+        cpacketize::sink = [&](const int8_t *p, size_t bytes, const std::complex<float> *phase, size_t n) {
+            const hdr0 *h = reinterpret_cast<const hdr0 *>(p);
+            uint64_t fnv = 1469598103934665603ull;
+            for (size_t i = 0; i < bytes; ++i) { fnv ^= (uint8_t)p[i]; fnv *= 1099511628211ull; }
+            for (size_t i = 0; i < n * sizeof(std::complex<float>); ++i) { fnv ^= reinterpret_cast<const uint8_t *>(phase)[i]; fnv *= 1099511628211ull; }
+            std::printf("packet seq %u N %u L %u bytes %zu digest %016llx\n", h->globalseqn, h->N, h->L, bytes, (unsigned long long)fnv);
+            badhdr += (h->N != (uint32_t)(1 + nsig)) + (h->L != (uint32_t)L);
+            ++npk;
+        };
+        ccoherent eng(&rdev, &dv, &rn, 8, mode, batch, &sh);
+        if (!eng.ok() || !eng.enable_batching(batch)) { std::printf("engine unavailable\nDEMO FAILED\n"); return 1; }
+        const int nb = std::max(1, blocks / batch);
+        bool ok = true;
+        auto fill = [&](int b) { for (auto *d : dv) d->requestfft(); return eng.fill_batch(b & 1, batch, [&](int) { src.advance(); }); };
+        ok = fill(0) && eng.submit_batch(0, batch, 0);
+        for (int b = 1; b < nb && ok; ++b) {
+            ok = fill(b) && eng.submit_batch(b & 1, batch, 0);          // batch b computes while batch b - 1 is exchanged and fetched
+            ok = ok && eng.collect_batch((b - 1) & 1);
+        }
+        ok = ok && eng.collect_batch((nb - 1) & 1);
+        const csynth_params *pp = src.get_params();
+        int badlag = 0;
+        const int per = nsig / ranks, lo = sh.id ? rank * per : 0, hi = sh.id ? lo + per : nsig;
+        for (int k = lo; k < hi; ++k) badlag += ((long)dv[k]->get_lagp()->lag != (long)pp->d[k]);      // this process's own devices got their lags
+        // blocks this rank assembled: runs of ceil(batch / ranks) per batch
+        const int bpr = (batch + ranks - 1) / ranks, mine = std::max(0, std::min(bpr, batch - rank * bpr));
+        const size_t expect = (size_t)nb * (size_t)(sh.id ? mine : batch);
+        std::printf("engine batches: rank %d of %d on device %d, %d batches x %d blocks, published %zu packets (expected %zu), own lags %s\n", rank, ranks, device, nb, batch,
+                    npk, expect, badlag ? "MISMATCH" : "ok");
+        const bool fail = !ok || badlag || badhdr || npk != expect;
+        cpacketize::sink = nullptr;
+        cpacketize::cleanup();
+        std::printf("%s\n", fail ? "DEMO FAILED" : "DEMO OK");
+        return fail ? 1 : 0;
     }
 
     csynthsource source(nsig, L, csynth_config_seed(1), dmax, false);

@@ -340,6 +340,28 @@ typedef struct crsdr_xop {
 int crsdr_exchange_schedule(int nranks, int rank, int nblocks, int mode, int nrows, int blocksize, size_t packet_stride,
                             crsdr_xop *ops, int capacity, int *count);
 
+/* ---- a sharded plan and its exchange as ONE engine: what a C++ host with one process per GPU runs (host/ccoherent.cc with
+ * ranks > 1; the loop of src/ccoherent.cc:245-294 a batch at a time, rows split over the GPUs of the node).
+ * crsdr_exchange_bind_plan allocates, once, everything the exchange of the plan's batches needs on the device -- two ring-buffered
+ * sets of: the send slots [max_batch][slot_stride] the plan writes its rows and tails into, the receive staging, the
+ * bpr = ceil(max_batch / nranks) packets this rank assembles per batch and their scalars blocks -- plus a side stream for the
+ * exchange, so the host handles no device memory and no stream.  The plan must own rank's slab (row_begin = 1 + rank * per,
+ * row_count = per) on the exchange's device.  Afterwards the plan is driven through the two calls below only. */
+int crsdr_exchange_bind_plan(crsdr_exchange *x, crsdr_plan *plan, int mode /* CRSDR_XCHG_* */);
+/* crsdr_plan_submit_batch (same arguments) into the next set, then crsdr_exchange_batch on the side stream: everything is enqueued
+ * on return; the exchange of this batch runs under the compute of the next one.  At most two batches may be outstanding. */
+int crsdr_exchange_submit_batch(crsdr_exchange *x, const void *rows, int mem_kind, int nblocks, size_t block_stride, const uint32_t *readcnt,
+                                const uint8_t *lag_mask, uint32_t seq, uint32_t flags);
+/* Waits for the OLDEST outstanding batch and copies what this rank assembled of it to host memory: blocks [*first, *first + *count)
+ * of the batch (crsdr_exchange_rooted_blocks; count may be 0) -- packet j at packets + j * host_packet_stride, its scalars block
+ * (int32 lag[N] | float mag[N] | float frac[N] | float phasor[N][2], 20 * nrows bytes) at scalars + j * host_scalars_stride.
+ * own_tails: {lag, mag, frac, phasor} of this rank's OWN rows for every block of the batch -- block t at own_tails + t * host_tails_stride
+ * as  int32 lag[per] | float mag[per] | float frac[per] | float phasor[per][2]  (20 * per bytes): what csdrdevice::set_lag needs on the
+ * process that reads those dongles (src/ccoherent.cc:232-233), whichever rank assembles the block; *nblocks = blocks in the batch.
+ * Any pointer may be NULL.  Reports a kernel-side error like crsdr_plan_fetch_wait does (the plan is rolled back). */
+int crsdr_exchange_fetch_rooted(crsdr_exchange *x, int8_t *packets, size_t host_packet_stride, void *scalars, size_t host_scalars_stride,
+                                void *own_tails, size_t host_tails_stride, int *first, int *count, int *nblocks);
+
 /* With profiling enabled (CRSDR_PROFILE_SUBMIT): elapsed GPU milliseconds on the plan's stream
  * between the start and the end of the most recent submit. */
 int crsdr_plan_last_elapsed_ms(crsdr_plan *plan, float *ms);

@@ -217,3 +217,27 @@ def test_batched_streaming_engine_shows_ring_overruns_in_the_header_readcnts(hos
     import re
     m = re.search(r"(\d+) packets, (\d+) read-counter jumps \((\d+) blocks skipped\), (\d+) backwards, (\d+) ring overruns", slow.stdout)
     assert m and int(m.group(2)) > 0 and 0 < int(m.group(3)) <= int(m.group(5)) and int(m.group(4)) == 0
+
+
+@pytest.mark.gpu
+def test_cpp_engine_one_process_per_gpu_self_exchange_equals_the_unsharded_engine(host_build, tmp_path):
+    # coherent_demo --engine-batches: the C++ host of the multi-GPU run -- ccoherent over a sharded plan (row_begin / row_count),
+    # crsdr_exchange_bind_plan / _submit_batch / _fetch_rooted (RCCL under the C ABI), the rank's rooted blocks through
+    # cpacketize::publish.  A one-GPU box can run ONE rank (RCCL refuses two ranks on a device): with CRSDR_XCHG_SELF=1 that
+    # rank's chunk goes through ncclSend / ncclRecv to itself, so communicator, grouped send / recv, assembly and the engine's
+    # bookkeeping all run; its packets and phase-factor payloads must equal the unsharded batched engine's, digest for digest.
+    exe = os.path.join(host_build, "coherent_demo")
+    args = ["--engine-batches", "--nsig", "6", "--blocks", "24", "--batch", "8"]
+    plain = subprocess.run([exe] + args, capture_output=True, text=True, timeout=300)
+    print(plain.stdout[-2000:], plain.stderr[-2000:])
+    assert plain.returncode == 0 and "DEMO OK" in plain.stdout, plain.stdout + plain.stderr
+    idf = tmp_path / "xid"
+    for mode_env in ({"CRSDR_XCHG_SELF": "1"}, {}):          # through the transport, and with the own chunk read straight from the send slots
+        if idf.exists():
+            idf.unlink()
+        shard = subprocess.run([exe] + args + ["--ranks", "1", "--rank", "0", "--device", "0", "--id-file", str(idf)], capture_output=True, text=True, timeout=300,
+                               env=dict(os.environ, **mode_env))
+        print(shard.stdout[-2000:], shard.stderr[-2000:])
+        assert shard.returncode == 0 and "DEMO OK" in shard.stdout, shard.stdout + shard.stderr
+        dig = lambda out: sorted(ln for ln in out.splitlines() if ln.startswith("packet seq"))
+        assert len(dig(plain.stdout)) == 24 and dig(plain.stdout) == dig(shard.stdout)
