@@ -268,22 +268,31 @@ __device__ __forceinline__ void shifted_vecs(uint4 (&sv)[U], const int8_t *__res
     }
 }
 
-// one word = two samples of s . conj(r): re += I.rI + Q.rQ, imp += Q.rI, imn += I.rQ (im = imp - imn once, at the end).
-// Six instructions per word: the byte swap is ONE v_perm_b32 (the shift / mask / or form compiled to three), and the
-// negative part has its own accumulator (accumulating "im -= dot" cost a zero and a subtraction per word): 10 -> 6.
-__device__ __forceinline__ void dot_word3(uint32_t s, uint32_t r, int &re, int &imp, int &imn)
+// one word = two samples of s . conj(r).  With the reference word's I / Q bytes swapped, rs = [rQ0 rI0 rQ1 rI1]:
+//     re += dot4(s, r)          = I.rI + Q.rQ
+//     cr += dot4(s, rs)         = I.rQ + Q.rI
+//     nq += dot4(s, rs & 0x00FF00FF) = I.rQ                         ->  im = Q.rI - I.rQ = cr - 2 nq, once, after the sums
+// THREE instructions per signal word; the swap (ONE v_perm_b32) and the mask are per REFERENCE word, i.e. they do not depend
+// on the row (r02: perm of the signal word + two masks of the reference word + three dot4 = six per signal word).
+// Ranges at B <= 16384: |re|, |cr| <= 8192 * 2 * 128^2 = 2^28, |nq| <= 2^27 -- exact in int32, and so is cr - 2 nq.
+__device__ __forceinline__ uint32_t ref_swap(uint32_t r) { return __builtin_amdgcn_perm(r, r, 0x02030001u); }   // [rQ0 rI0 rQ1 rI1]
+__device__ __forceinline__ void dot_word3(uint32_t s, uint32_t r, uint32_t rs, uint32_t rsq, int &re, int &cr, int &nq)
 {
-    // bytes of a word: [I0 Q0 I1 Q1]
-    const uint32_t sw = __builtin_amdgcn_perm(s, s, 0x02030001u);                 // [Q0 I0 Q1 I1]
-    re = __builtin_amdgcn_sdot4((int)s, (int)r, re, false);                       // I.rI + Q.rQ
-    imp = __builtin_amdgcn_sdot4((int)sw, (int)(r & 0x00FF00FFu), imp, false);    // Q.rI
-    imn = __builtin_amdgcn_sdot4((int)sw, (int)(r & 0xFF00FF00u), imn, false);    // I.rQ
+    re = __builtin_amdgcn_sdot4((int)s, (int)r, re, false);
+    cr = __builtin_amdgcn_sdot4((int)s, (int)rs, cr, false);
+    nq = __builtin_amdgcn_sdot4((int)s, (int)rsq, nq, false);
+}
+// same sums from the reference word alone (forms its swapped / masked forms here: five instructions per word)
+__device__ __forceinline__ void dot_word3(uint32_t s, uint32_t r, int &re, int &cr, int &nq)
+{
+    const uint32_t rs = ref_swap(r);
+    dot_word3(s, r, rs, rs & 0x00FF00FFu, re, cr, nq);
 }
 __device__ __forceinline__ void dot_word(uint32_t s, uint32_t r, int &re, int &im)
 {
-    int imp = 0, imn = 0;
-    dot_word3(s, r, re, imp, imn);
-    im += imp - imn;
+    int cr = 0, nq = 0;
+    dot_word3(s, r, re, cr, nq);
+    im += cr - 2 * nq;
 }
 
 // U: 16-byte vectors a thread has in flight per loop iteration (4: one 16 KiB chunk per pass of the workgroup; 8: the long
@@ -300,7 +309,7 @@ __global__ __launch_bounds__(kAlignThreads) void k_phase_dot(AlignArgs a)
     const uint32_t *r32 = reinterpret_cast<const uint32_t *>(blk);
     const int d = align_shift(a, row, t);
     // int32 partials are safe (<= 2^16 per word, <= 2^13 words per thread)
-    int re = 0, im = 0, imp = 0, imn = 0;
+    int re = 0, im = 0, cr = 0, nq = 0;
     // long rows are split over grid.z chunks (one chunk for B <= 16 KiB)
     const int nchunk = gridDim.z, v_lo = (int)(((long long)(B / 16) * blockIdx.z) / nchunk),
               v_hi = (int)(((long long)(B / 16) * (blockIdx.z + 1)) / nchunk);
@@ -318,14 +327,14 @@ __global__ __launch_bounds__(kAlignThreads) void k_phase_dot(AlignArgs a)
 #pragma unroll
             for (int q = 0; q < U; ++q) {
                 if (i0 + q * kAlignThreads < v_hi) {
-                    dot_word3(sv[q].x, rv[q].x ^ a.xor80, re, imp, imn);
-                    dot_word3(sv[q].y, rv[q].y ^ a.xor80, re, imp, imn);
-                    dot_word3(sv[q].z, rv[q].z ^ a.xor80, re, imp, imn);
-                    dot_word3(sv[q].w, rv[q].w ^ a.xor80, re, imp, imn);
+                    dot_word3(sv[q].x, rv[q].x ^ a.xor80, re, cr, nq);
+                    dot_word3(sv[q].y, rv[q].y ^ a.xor80, re, cr, nq);
+                    dot_word3(sv[q].z, rv[q].z ^ a.xor80, re, cr, nq);
+                    dot_word3(sv[q].w, rv[q].w ^ a.xor80, re, cr, nq);
                 }
             }
         }
-        im = imp - imn;
+        im = cr - 2 * nq;
     } else {
         for (int i = 4 * v_lo + tid; i < 4 * v_hi; i += kAlignThreads) {
             const uint32_t s = (d == 0) ? (s32[i] ^ a.xor80) : shifted_word(s32, i, d, L, a.xor80);
@@ -551,7 +560,9 @@ constexpr int kFusedSpinLimit = 2048;      // polls of ~1 us each before a workg
 // FULL: B == 16384, every thread owns exactly four 16-byte vectors of the row (no bounds checks in the hot loops)
 // XOR: the input is offset binary (CRSDR_OFFSET_BINARY); false folds the 40-odd "^ xor80" of a thread away (5 % of its VALU work)
 template <bool FULL, bool XOR>
-__global__ __launch_bounds__(kAlignThreads, 8) void k_align_fused(AlignArgs a_, FusedSync fs)
+// amdgpu_waves_per_eu(8, 8): eight waves per SIMD is what 59 VGPRs give; told so, the compiler keeps its ~96 scalar registers instead of
+// squeezing into the 80 a tenth wave would need (which no VGPR budget here allows) and spilling 18 - 41 of them through v_writelane / v_readlane
+__global__ __launch_bounds__(kAlignThreads) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_align_fused(AlignArgs a_, FusedSync fs)
 {
     AlignArgs a = a_;
     a.xor80 = XOR ? a_.xor80 : 0u;                 // a compile-time zero without XOR
@@ -655,18 +666,18 @@ __global__ __launch_bounds__(kAlignThreads, 8) void k_align_fused(AlignArgs a_, 
 #pragma unroll
     for (int q = 0; q < 4; ++q) sv[q] = make_uint4(sv[q].x ^ a.xor80, sv[q].y ^ a.xor80, sv[q].z ^ a.xor80, sv[q].w ^ a.xor80);
     if (a.refnoise) {
-        int re = 0, imp = 0, imn = 0;
+        int re = 0, cr = 0, nq = 0;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int i = tid + q * kAlignThreads;
             if (FULL || i < nvec) {
-                dot_word3(sv[q].x, rv[q].x ^ a.xor80, re, imp, imn);
-                dot_word3(sv[q].y, rv[q].y ^ a.xor80, re, imp, imn);
-                dot_word3(sv[q].z, rv[q].z ^ a.xor80, re, imp, imn);
-                dot_word3(sv[q].w, rv[q].w ^ a.xor80, re, imp, imn);
+                dot_word3(sv[q].x, rv[q].x ^ a.xor80, re, cr, nq);
+                dot_word3(sv[q].y, rv[q].y ^ a.xor80, re, cr, nq);
+                dot_word3(sv[q].z, rv[q].z ^ a.xor80, re, cr, nq);
+                dot_word3(sv[q].w, rv[q].w ^ a.xor80, re, cr, nq);
             }
         }
-        int im = imp - imn;
+        int im = cr - 2 * nq;
         // B <= 16384 here: |sum| <= 8192 * 2 * 127^2 < 2^28, so the wave sums are exact in 32 bits (six DPP adds each)
         re = wave_sum_lane63(re);
         im = wave_sum_lane63(im);

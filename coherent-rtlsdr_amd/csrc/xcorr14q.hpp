@@ -18,7 +18,11 @@ namespace crsdr {
 namespace x14p {
 
 constexpr int QG = 256;                                       // threads per row group
-constexpr int LDSQ_BYTES = LDS_ELEMS * 8 + 2 * 512 + 64;      // image + a reduction scratch per group + sync words (sizeof(QSync) <= 64)
+// per-group scratch behind the image: the four waves' argmax candidates (max, first index, the peak's in-wave neighbours: 64 B)
+// and the magnitudes of every wave's first and last lane (4 waves x 2 lanes x 64 values: a peak on a wave edge has its
+// neighbour there); k_rows14_cf32q only uses the sync words
+constexpr int QSCR_BYTES = 64 + 4 * 2 * 64 * 4;
+constexpr int LDSQ_BYTES = LDS_ELEMS * 8 + 2 * QSCR_BYTES + 64;      // image + scratch per group + sync words (sizeof(QSync) <= 64)
 constexpr int kQSpinLimit = 1 << 18;
 #ifndef Q_PRIO
 #define Q_PRIO 3
@@ -34,7 +38,9 @@ struct QSync {
     int err;        // a bounded wait ran out
     int next[2];    // the item each group takes after its current one (drawn one row ahead by the group's first lane)
     int spin_limit; // polls a wait may take (kQSpinLimit; a test forces 0 to see the error path)
+    int arrive[2];  // waves of each group that have published their argmax candidate (monotonic: the fourth of a row finishes it)
 };
+static_assert(sizeof(QSync) <= 64, "QSync must fit the 64 bytes reserved behind the scratch");
 
 #ifdef CRSDR_QDEBUG      // tools/k1_pair.hip: cycles workgroup 0's waves spend in group barriers [1] / waiting for the image [2], total [0]
 __device__ unsigned long long *dbg__ = nullptr;
@@ -191,6 +197,93 @@ __device__ __forceinline__ float q_wave_max63(float wm)
     return wm;      // valid in lane 63
 }
 
+// minimum of v over the 64 lanes (wave-uniform result): the same six DPP steps as q_wave_max63, then lane 63 read back
+__device__ __forceinline__ int q_wave_min(int v)
+{
+    v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x111, 0xf, 0xf, false));
+    v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x112, 0xf, 0xf, false));
+    v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x114, 0xf, 0xf, false));
+    v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x118, 0xf, 0xf, false));
+    v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x142, 0xa, 0xf, false));
+    v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x143, 0xc, 0xf, false));
+    return __builtin_amdgcn_readlane(v, 63);
+}
+// (idx < 32 ? m0[idx] : m1[idx - 32]) for a WAVE-UNIFORM idx: a tree of scalar branches ending in one move.  (Written as an
+// array subscript -- or as a tree of ?: the optimiser recognises as one -- the two arrays go to scratch memory; 64 compares and
+// selects would do, at 64 vector instructions per wave and row.)  The asm keeps every leaf a plain register read.
+__device__ __forceinline__ float q_pick(const float (&m0)[32], const float (&m1)[32], int idx)
+{
+    float r = 0.0f;
+    switch (__builtin_amdgcn_readfirstlane(idx)) {
+    case 0: asm volatile("v_mov_b32 %0, %1" : "=v"(r) : "v"(m0[0])); break;
+    case 1: asm volatile("v_mov_b32 %0, %1" : "=v"(r) : "v"(m0[1])); break;
+    case 2: asm volatile("v_mov_b32 %0, %1" : "=v"(r) : "v"(m0[2])); break;
+    case 3: asm volatile("v_mov_b32 %0, %1" : "=v"(r) : "v"(m0[3])); break;
+    case 4: asm volatile("v_mov_b32 %0, %1" : "=v"(r) : "v"(m0[4])); break;
+    case 5: asm volatile("v_mov_b32 %0, %1" : "=v"(r) : "v"(m0[5])); break;
+    case 6: asm volatile("v_mov_b32 %0, %1" : "=v"(r) : "v"(m0[6])); break;
+    case 7: asm volatile("v_mov_b32 %0, %1" : "=v"(r) : "v"(m0[7])); break;
+    case 8: asm volatile("v_mov_b32 %0, %1" : "=v"(r) : "v"(m0[8])); break;
+    case 9: asm volatile("v_mov_b32 %0, %1" : "=v"(r) : "v"(m0[9])); break;
+    case 10: asm volatile("v_mov_b32 %0, %1" : "=v"(r) : "v"(m0[10])); break;
+    case 11: asm volatile("v_mov_b32 %0, %1" : "=v"(r) : "v"(m0[11])); break;
+    case 12: asm volatile("v_mov_b32 %0, %1" : "=v"(r) : "v"(m0[12])); break;
+    case 13: asm volatile("v_mov_b32 %0, %1" : "=v"(r) : "v"(m0[13])); break;
+    case 14: asm volatile("v_mov_b32 %0, %1" : "=v"(r) : "v"(m0[14])); break;
+    case 15: asm volatile("v_mov_b32 %0, %1" : "=v"(r) : "v"(m0[15])); break;
+    case 16: asm volatile("v_mov_b32 %0, %1" : "=v"(r) : "v"(m0[16])); break;
+    case 17: asm volatile("v_mov_b32 %0, %1" : "=v"(r) : "v"(m0[17])); break;
+    case 18: asm volatile("v_mov_b32 %0, %1" : "=v"(r) : "v"(m0[18])); break;
+    case 19: asm volatile("v_mov_b32 %0, %1" : "=v"(r) : "v"(m0[19])); break;
+    case 20: asm volatile("v_mov_b32 %0, %1" : "=v"(r) : "v"(m0[20])); break;
+    case 21: asm volatile("v_mov_b32 %0, %1" : "=v"(r) : "v"(m0[21])); break;
+    case 22: asm volatile("v_mov_b32 %0, %1" : "=v"(r) : "v"(m0[22])); break;
+    case 23: asm volatile("v_mov_b32 %0, %1" : "=v"(r) : "v"(m0[23])); break;
+    case 24: asm volatile("v_mov_b32 %0, %1" : "=v"(r) : "v"(m0[24])); break;
+    case 25: asm volatile("v_mov_b32 %0, %1" : "=v"(r) : "v"(m0[25])); break;
+    case 26: asm volatile("v_mov_b32 %0, %1" : "=v"(r) : "v"(m0[26])); break;
+    case 27: asm volatile("v_mov_b32 %0, %1" : "=v"(r) : "v"(m0[27])); break;
+    case 28: asm volatile("v_mov_b32 %0, %1" : "=v"(r) : "v"(m0[28])); break;
+    case 29: asm volatile("v_mov_b32 %0, %1" : "=v"(r) : "v"(m0[29])); break;
+    case 30: asm volatile("v_mov_b32 %0, %1" : "=v"(r) : "v"(m0[30])); break;
+    case 31: asm volatile("v_mov_b32 %0, %1" : "=v"(r) : "v"(m0[31])); break;
+    case 32: asm volatile("v_mov_b32 %0, %1" : "=v"(r) : "v"(m1[0])); break;
+    case 33: asm volatile("v_mov_b32 %0, %1" : "=v"(r) : "v"(m1[1])); break;
+    case 34: asm volatile("v_mov_b32 %0, %1" : "=v"(r) : "v"(m1[2])); break;
+    case 35: asm volatile("v_mov_b32 %0, %1" : "=v"(r) : "v"(m1[3])); break;
+    case 36: asm volatile("v_mov_b32 %0, %1" : "=v"(r) : "v"(m1[4])); break;
+    case 37: asm volatile("v_mov_b32 %0, %1" : "=v"(r) : "v"(m1[5])); break;
+    case 38: asm volatile("v_mov_b32 %0, %1" : "=v"(r) : "v"(m1[6])); break;
+    case 39: asm volatile("v_mov_b32 %0, %1" : "=v"(r) : "v"(m1[7])); break;
+    case 40: asm volatile("v_mov_b32 %0, %1" : "=v"(r) : "v"(m1[8])); break;
+    case 41: asm volatile("v_mov_b32 %0, %1" : "=v"(r) : "v"(m1[9])); break;
+    case 42: asm volatile("v_mov_b32 %0, %1" : "=v"(r) : "v"(m1[10])); break;
+    case 43: asm volatile("v_mov_b32 %0, %1" : "=v"(r) : "v"(m1[11])); break;
+    case 44: asm volatile("v_mov_b32 %0, %1" : "=v"(r) : "v"(m1[12])); break;
+    case 45: asm volatile("v_mov_b32 %0, %1" : "=v"(r) : "v"(m1[13])); break;
+    case 46: asm volatile("v_mov_b32 %0, %1" : "=v"(r) : "v"(m1[14])); break;
+    case 47: asm volatile("v_mov_b32 %0, %1" : "=v"(r) : "v"(m1[15])); break;
+    case 48: asm volatile("v_mov_b32 %0, %1" : "=v"(r) : "v"(m1[16])); break;
+    case 49: asm volatile("v_mov_b32 %0, %1" : "=v"(r) : "v"(m1[17])); break;
+    case 50: asm volatile("v_mov_b32 %0, %1" : "=v"(r) : "v"(m1[18])); break;
+    case 51: asm volatile("v_mov_b32 %0, %1" : "=v"(r) : "v"(m1[19])); break;
+    case 52: asm volatile("v_mov_b32 %0, %1" : "=v"(r) : "v"(m1[20])); break;
+    case 53: asm volatile("v_mov_b32 %0, %1" : "=v"(r) : "v"(m1[21])); break;
+    case 54: asm volatile("v_mov_b32 %0, %1" : "=v"(r) : "v"(m1[22])); break;
+    case 55: asm volatile("v_mov_b32 %0, %1" : "=v"(r) : "v"(m1[23])); break;
+    case 56: asm volatile("v_mov_b32 %0, %1" : "=v"(r) : "v"(m1[24])); break;
+    case 57: asm volatile("v_mov_b32 %0, %1" : "=v"(r) : "v"(m1[25])); break;
+    case 58: asm volatile("v_mov_b32 %0, %1" : "=v"(r) : "v"(m1[26])); break;
+    case 59: asm volatile("v_mov_b32 %0, %1" : "=v"(r) : "v"(m1[27])); break;
+    case 60: asm volatile("v_mov_b32 %0, %1" : "=v"(r) : "v"(m1[28])); break;
+    case 61: asm volatile("v_mov_b32 %0, %1" : "=v"(r) : "v"(m1[29])); break;
+    case 62: asm volatile("v_mov_b32 %0, %1" : "=v"(r) : "v"(m1[30])); break;
+    case 63: asm volatile("v_mov_b32 %0, %1" : "=v"(r) : "v"(m1[31])); break;
+    default: break;
+    }
+    return r;
+}
+
 // grid: one workgroup per CU; items = owned rows x blocks, item (2k + g) * gridDim.x + blockIdx.x goes to group g
 __global__ __launch_bounds__(2 * QG, 1) void k_xcorr_lag14q(XcorrArgs a, const float2 *__restrict__ twA_, const float2 *__restrict__ twB_,
                                                            int row_count, int *__restrict__ errflag, unsigned int *__restrict__ work,
@@ -201,10 +294,11 @@ __global__ __launch_bounds__(2 * QG, 1) void k_xcorr_lag14q(XcorrArgs a, const f
     c2 *A = reinterpret_cast<c2 *>(smem);
     float4 *A4 = reinterpret_cast<float4 *>(smem);
     const int g = threadIdx.x >> 8, tid = threadIdx.x & (QG - 1);
-    float *red = reinterpret_cast<float *>(smem + (size_t)LDS_ELEMS * 8 + 512 * g);
+    float *red = reinterpret_cast<float *>(smem + (size_t)LDS_ELEMS * 8 + QSCR_BYTES * g);      // [0..3] wave max, [4..7] its first index, [8..11] / [12..15] the neighbours
     int *redi = reinterpret_cast<int *>(red);
-    QSync *sy = reinterpret_cast<QSync *>(smem + (size_t)LDS_ELEMS * 8 + 1024);
-    if (threadIdx.x == 0) { sy->owner = 0; sy->relcnt = 0; sy->bar[0] = 0; sy->bar[1] = 0; sy->err = 0; sy->next[0] = 0; sy->next[1] = 0; sy->spin_limit = spin_limit; }
+    float *edge = red + 16;                                                                      // [wave][first lane, last lane][half * 32 + i]
+    QSync *sy = reinterpret_cast<QSync *>(smem + (size_t)LDS_ELEMS * 8 + 2 * QSCR_BYTES);
+    if (threadIdx.x == 0) { sy->owner = 0; sy->relcnt = 0; sy->bar[0] = 0; sy->bar[1] = 0; sy->err = 0; sy->next[0] = 0; sy->next[1] = 0; sy->spin_limit = spin_limit; sy->arrive[0] = 0; sy->arrive[1] = 0; }
     __syncthreads();
     int gen = 0;
 #ifdef CRSDR_QDEBUG
@@ -248,6 +342,10 @@ __global__ __launch_bounds__(2 * QG, 1) void k_xcorr_lag14q(XcorrArgs a, const f
         float4 ra[8], rb[8];
         q_refspec_load(ra, refspec4, vt0, 0);
         q_barrier(sy, g, gen, 0);
+        // the group's next item, drawn one row ahead: the atomic goes out here, its result is parked in LDS before the window's
+        // second barrier and read by everybody after it (the next write follows the next row's first barrier on either path)
+        int drawn = 0;
+        if (tid == 0) drawn = 2 * (int)gridDim.x + (int)(atomicAdd(work, 1u) - work_base);
         pass1_forward(A, wB, vt0);
         pass1_forward(A, wB, vt1);
         wave_lds_sync();
@@ -261,8 +359,8 @@ __global__ __launch_bounds__(2 * QG, 1) void k_xcorr_lag14q(XcorrArgs a, const f
         wave_lds_sync();
         pass1_inverse(A, wB, vt0);
         pass1_inverse(A, wB, vt1);
+        if (tid == 0) sy->next[g] = drawn;
         q_barrier(sy, g, gen, 1);
-        if (tid == 0) sy->next[g] = 2 * (int)gridDim.x + (int)(atomicAdd(work, 1u) - work_base);   // read after this row's last barrier
         float m0[32], m1[32];
         {
             c2 v[32], v2[32];
@@ -270,73 +368,78 @@ __global__ __launch_bounds__(2 * QG, 1) void k_xcorr_lag14q(XcorrArgs a, const f
             q_p0i_load(v2, A, vt1);
             q_release(sy);                               // from here on this row is in registers
             __builtin_amdgcn_s_setprio(0);
-            q_p0i_compute(m0, v, twA, vt0);
-            q_p0i_compute(m1, v2, twA, vt1);
+            int vb0 = tid, vb1 = tid + QG;               // opaque again: the column-twiddle addresses of the first pass would otherwise be kept (spilled) for this one
+            asm volatile("" : "+v"(vb0), "+v"(vb1));
+            q_p0i_compute(m0, v, twA, vb0);
+            q_p0i_compute(m1, v2, twA, vb1);
         }
-        // maximum value, then its first index (natural index of output i of virtual thread vt: i * 512 + vt)
+        // ---- argmax without a group barrier ------------------------------------------------------------------------------------
+        // Each wave reduces its own 64 x 64 magnitudes to a candidate -- maximum VALUE first (v_max3, six DPP steps), then the first
+        // index at which its lanes hold it (natural index of output i of virtual thread vt: i * 512 + vt; volk_32f_index_max_32u keeps
+        // the first strict maximum) -- and parks it in LDS with the peak's two neighbours where they sit in the same wave; the
+        // magnitudes of the wave's first and last lane go to the edge table, where a peak on a wave edge finds its neighbour.  The
+        // LAST of the four waves to arrive combines the candidates and publishes; nobody waits for anybody (r02: two group barriers per
+        // row, 12 % of a wave's time, spun through beside the other group's window).  A wave cannot overwrite its candidate before
+        // the finisher has read it: the next row's epilogue lies behind that row's two window barriers, which the finisher joins.
         float tm = fmaxf(m0[0], m1[0]);
 #pragma unroll
         for (int i = 1; i < 32; ++i) tm = fmaxf(tm, fmaxf(m0[i], m1[i]));
-        const float wm = q_wave_max63(tm);
-        if (tid == 0) redi[16] = 0x7fffffff;
-        if ((tid & 63) == 63) red[tid >> 6] = wm;
-        q_barrier(sy, g, gen, 2);
-        float gm = red[0];
-#pragma unroll
-        for (int wv = 1; wv < QG / 64; ++wv) gm = fmaxf(gm, red[wv]);
-        if (tm == gm) {
-            int bi = 0x7fffffff;
+        const int lane = tid & 63, wv = tid >> 6;
+        const float wm = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(q_wave_max63(tm)), 63));
+        int bi = 0x7fffffff;
+        if (tm == wm) {
 #pragma unroll
             for (int i = 31; i >= 0; --i) {
-                bi = (m1[i] == gm) ? i * 512 + vt1 : bi;
-                bi = (m0[i] == gm) ? i * 512 + vt0 : bi;      // vt0 < vt1: the lower index wins at the same i
-            }
-            atomicMin(&redi[16], bi);
-        }
-        q_barrier(sy, g, gen, 3);
-        int gi = redi[16];
-        if ((unsigned)gi >= (unsigned)N) gi = 0;
-        const int pc = gi & 511, pi_ = gi >> 9;
-        const bool in_wave = ((pc & 63) != 0) && ((pc & 63) != 63);       // group-uniform
-        if (in_wave) {
-            if ((tid >> 6) == ((pc & (QG - 1)) >> 6)) {
-                float mine = 0.f;
-#pragma unroll
-                for (int i = 0; i < 32; ++i) mine = (i == pi_) ? ((pc >> 8) ? m1[i] : m0[i]) : mine;
-                const float ym = __shfl_up(mine, 1, 64), yp = __shfl_down(mine, 1, 64);
-                if (tid == (pc & (QG - 1))) {
-                    float D = 0.0f;
-                    const float den = (ym - 2.0f * gm) + yp;
-                    if (den != 0.0f) D = (0.5f * (ym - yp)) / den;
-                    xcorr_publish(a, row, t, gi - L, sqrtf(gm / (float)L) * kInvScale2, D);
-                }
-            }
-        } else {
-            const int nl = gi - 1, nr = gi + 1;
-            if (gi > 0 && ((nl & 511) & (QG - 1)) == tid) {
-                float ml = 0.f;
-#pragma unroll
-                for (int i = 0; i < 32; ++i) ml = (i == (nl >> 9)) ? (((nl & 511) >> 8) ? m1[i] : m0[i]) : ml;
-                red[32] = ml;
-            }
-            if (gi < N - 1 && ((nr & 511) & (QG - 1)) == tid) {
-                float mr = 0.f;
-#pragma unroll
-                for (int i = 0; i < 32; ++i) mr = (i == (nr >> 9)) ? (((nr & 511) >> 8) ? m1[i] : m0[i]) : mr;
-                red[33] = mr;
-            }
-            q_barrier(sy, g, gen, 4);
-            if (tid == 0) {
-                float D = 0.0f;
-                if (gi > 0 && gi < N - 1) {
-                    const float ym = red[32], yp = red[33];
-                    const float den = (ym - 2.0f * gm) + yp;
-                    if (den != 0.0f) D = (0.5f * (ym - yp)) / den;
-                }
-                xcorr_publish(a, row, t, gi - L, sqrtf(gm / (float)L) * kInvScale2, D);
+                bi = (m1[i] == wm) ? i * 512 + vt1 : bi;
+                bi = (m0[i] == wm) ? i * 512 + vt0 : bi;      // vt0 < vt1: the lower index wins at the same i
             }
         }
-        item = sy->next[g];       // drawn after this row's second barrier, read after its last one
+        const int wbi = q_wave_min(bi);                       // wave-uniform; 0x7fffffff: no lane compared equal (an all-NaN wave)
+        if (lane == 0 || lane == 63) {
+            float4 *e4 = reinterpret_cast<float4 *>(edge + (wv * 2 + (lane ? 1 : 0)) * 64);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                e4[i] = make_float4(m0[4 * i], m0[4 * i + 1], m0[4 * i + 2], m0[4 * i + 3]);
+                e4[8 + i] = make_float4(m1[4 * i], m1[4 * i + 1], m1[4 * i + 2], m1[4 * i + 3]);
+            }
+        }
+        {
+            const int pcw = wbi & 511, piw = (wbi >> 9) & 31;
+            const float mine = q_pick(m0, m1, (pcw >> 8) * 32 + piw);     // every lane's magnitude at the candidate's output index and half
+            const float ym = __shfl_up(mine, 1, 64), yp = __shfl_down(mine, 1, 64);
+            if (lane == (pcw & 63)) { red[wv] = wm; redi[4 + wv] = wbi; red[8 + wv] = ym; red[12 + wv] = yp; }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        int arrived = 0;
+        if (lane == 0) arrived = __hip_atomic_fetch_add(&sy->arrive[g], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        arrived = __builtin_amdgcn_readfirstlane(arrived);
+        if ((arrived & 3) == 3) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            float gm = red[0];
+#pragma unroll
+            for (int w = 1; w < QG / 64; ++w) gm = fmaxf(gm, red[w]);
+            int gi = 0x7fffffff;
+#pragma unroll
+            for (int w = 0; w < QG / 64; ++w) gi = (red[w] == gm) ? min(gi, redi[4 + w]) : gi;
+            if ((unsigned)gi >= (unsigned)N) gi = 0;          // all-NaN row: defined as index 0
+            const int pc = gi & 511, ow = (pc & (QG - 1)) >> 6, ln = pc & 63;
+            float ym = red[8 + ow], yp = red[12 + ow];        // the owner wave's own lanes pc -+ 1 ...
+            if (ln == 0 && gi > 0) {                          // ... unless the peak sits on a wave edge: the neighbour is another wave's last / first lane
+                const int nl = gi - 1, cl = nl & 511;
+                ym = edge[(((cl & (QG - 1)) >> 6) * 2 + 1) * 64 + (cl >> 8) * 32 + (nl >> 9)];
+            }
+            if (ln == 63 && gi < N - 1) {
+                const int nr = gi + 1, cr = nr & 511;
+                yp = edge[(((cr & (QG - 1)) >> 6) * 2 + 0) * 64 + (cr >> 8) * 32 + (nr >> 9)];
+            }
+            float D = 0.0f;
+            if (gi > 0 && gi < N - 1) {
+                const float den = (ym - 2.0f * gm) + yp;
+                if (den != 0.0f) D = (0.5f * (ym - yp)) / den;
+            }
+            if (lane == 0) xcorr_publish(a, row, t, gi - L /* src/ccoherent.cc:232 */, sqrtf(gm / (float)L) * kInvScale2 /* :204 */, D);
+        }
+        item = sy->next[g];       // written before this row's second barrier; rewritten behind the next row's first
     }
 #ifdef CRSDR_QDEBUG
     if (dbg__ && blockIdx.x == 0 && (threadIdx.x & 63) == 0) atomicAdd(dbg__ + 0, (unsigned long long)(__builtin_readcyclecounter() - tk0__));
@@ -424,8 +527,8 @@ __global__ __launch_bounds__(2 * QG, 1) void k_rows14_cf32q(c2 *__restrict__ Y, 
     c2 *A = reinterpret_cast<c2 *>(smem);
     float4 *A4 = reinterpret_cast<float4 *>(smem);
     const int g = threadIdx.x >> 8, tid = threadIdx.x & (QG - 1);
-    QSync *sy = reinterpret_cast<QSync *>(smem + (size_t)LDS_ELEMS * 8 + 1024);
-    if (threadIdx.x == 0) { sy->owner = 0; sy->relcnt = 0; sy->bar[0] = 0; sy->bar[1] = 0; sy->err = 0; sy->next[0] = 0; sy->next[1] = 0; sy->spin_limit = spin_limit; }
+    QSync *sy = reinterpret_cast<QSync *>(smem + (size_t)LDS_ELEMS * 8 + 2 * QSCR_BYTES);
+    if (threadIdx.x == 0) { sy->owner = 0; sy->relcnt = 0; sy->bar[0] = 0; sy->bar[1] = 0; sy->err = 0; sy->next[0] = 0; sy->next[1] = 0; sy->spin_limit = spin_limit; sy->arrive[0] = 0; sy->arrive[1] = 0; }
     __syncthreads();
     int gen = 0;
     const int q = (int)blockIdx.x % nq, nlocal = 2 * ((int)gridDim.x / nq);           // this workgroup's queue; groups working on it
