@@ -224,26 +224,19 @@ static hipError_t launch_xcorr_lag(hipStream_t s, const XcorrArgs &a, int row_co
     return hipGetLastError();
 }
 
-// CRSDR_K1_VARIANT: "packed" (default) = xcorr14p.hpp, packed complex arithmetic; "scalar" = xcorr14.hpp, the same network
-// on scalar fp32 ops (bit-identical results).  (Two measured-slower experiments live in tools/: xcorr14h.hpp, half-row LDS images -- dead end (8) of DESIGN.md -- and
-// xcorr14w.hpp, 1024 threads per row with the radix-32 transforms shared by lane pairs -- dead end (11).)
+// CRSDR_K1_VARIANT (README, "switches"): "auto" (default) = the two-row kernel (q, xcorr14q.hpp) for launches with enough rows per
+// CU, the packed one-row kernel (p, xcorr14p.hpp) otherwise; "packed" / "q" force one of them.  Same arithmetic, identical bits.
+// (Measured-slower experiments live in tools/: xcorr14h.hpp, half-row LDS images -- dead end (8) of DESIGN.md --, xcorr14w.hpp,
+// 1024 threads per row -- dead end (11) --, and xcorr14_scalar.hpp, the scalar-fp32 twin of r01.)
 static char k1_variant()
 {
-    // unset / "auto": the two-row kernel (q) for launches with enough rows per CU, the packed one (p) otherwise
-    static const char v = [] { const char *e = getenv("CRSDR_K1_VARIANT"); return e ? e[0] : 'a'; }();
-    return v == 'k' ? 'p' : v;
+    static const char v = [] { const char *e = getenv("CRSDR_K1_VARIANT"); const char c = e ? e[0] : 'a'; return (c == 'p' || c == 'q') ? c : 'a'; }();
+    return v;
 }
 
 static hipError_t launch_ref_spectrum14(hipStream_t s, int nblocks, const int8_t *rows, size_t block_stride, const float2 *twA,
                                         const float2 *twB, float2 *refspec, uint32_t xor80)
 {
-    if (k1_variant() == 's') {   // scalar arithmetic (xcorr14.hpp); the packed kernels give identical bits
-        auto kern = x14::k_ref_spectrum14;
-        hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, x14::LDS_BYTES);
-        if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(kern, dim3(nblocks), dim3(x14::THREADS), x14::LDS_BYTES, s, rows, block_stride, twA, twB, (float4 *)refspec, xor80);
-        return hipGetLastError();
-    }
     auto kern = x14p::k_ref_spectrum14p;
     hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, x14::LDS_BYTES);
     if (e != hipSuccess) return e;
@@ -258,8 +251,7 @@ static hipError_t launch_xcorr_lag14(hipStream_t s, const XcorrArgs &a, int row_
     static const int cus = [] {
         int dev = 0, n = 0;
         if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 1) n = 256;
-        const char *e = getenv("CRSDR_K1_QGRID");
-        return e ? atoi(e) : n;
+        return n;
     }();
     const int items = row_count * a.nblocks;
     char variant = k1_variant();
@@ -268,14 +260,14 @@ static hipError_t launch_xcorr_lag14(hipStream_t s, const XcorrArgs &a, int row_
     if (variant == 'a') variant = items >= 12 * cus ? 'q' : 'p';
     if (variant == 'q' && !allow_q) variant = 'p';   // a plan whose two-row kernel once ran out of a bounded wait stays on the packed kernel
     if (used_q) *used_q = variant == 'q';
-    if (variant == 'p') {
+    if (variant != 'q') {
         auto kp = x14p::k_xcorr_lag14p;
         hipError_t ep = hipFuncSetAttribute((const void *)kp, hipFuncAttributeMaxDynamicSharedMemorySize, x14::LDS_BYTES);
         if (ep != hipSuccess) return ep;
         hipLaunchKernelGGL(kp, dim3(row_count, a.nblocks), dim3(x14::THREADS), x14::LDS_BYTES, s, a, twA, twB);
         return hipGetLastError();
     }
-    if (variant == 'q') {   // two rows per CU in opposite phases (xcorr14q.hpp), one persistent workgroup per CU
+    {   // two rows per CU in opposite phases (xcorr14q.hpp), one persistent workgroup per CU
         auto kq = x14p::k_xcorr_lag14q;
         hipError_t eq = hipFuncSetAttribute((const void *)kq, hipFuncAttributeMaxDynamicSharedMemorySize, x14p::LDSQ_BYTES);
         if (eq != hipSuccess) return eq;
@@ -291,11 +283,6 @@ static hipError_t launch_xcorr_lag14(hipStream_t s, const XcorrArgs &a, int row_
         if (el == hipSuccess) *work_base += (unsigned)items;      // a launch that ran advances the device counter by exactly its item count (xcorr14q.hpp)
         return el;
     }
-    auto kern = x14::k_xcorr_lag14;
-    hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, x14::LDS_BYTES);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(kern, dim3(row_count, a.nblocks), dim3(x14::THREADS), x14::LDS_BYTES, s, a, twA, twB);
-    return hipGetLastError();
 }
 
 template <int LOG2N, int DIR>
@@ -329,11 +316,10 @@ static hipError_t launch_op_fft(hipStream_t s, int howmany, float2 *out, const f
 // (row, tile) work items with the next item's loads in flight (longblock.hpp); CRSDR_LONG_PERSIST=0: one workgroup per item
 static int lb_grid(int nwork, bool stage_c = false)
 {
-    static const int per_cu_a = [] { const char *e = getenv("CRSDR_LONG_PERSIST"); return e ? atoi(e) : 2; }();
-    // stage C (reads only) is better off with one workgroup per item: measured r02, cfg5, per launch of 10.5 rows: 55 us against
-    // 61 us persistent (its reads alone run at 4.1 TB/s either way: 43 us); stage A (mostly stores) gains: 61 -> 52 us
-    static const int per_cu_c = [] { const char *e = getenv("CRSDR_LONG_PERSIST_C"); return e ? atoi(e) : 0; }();
-    const int per_cu = stage_c ? per_cu_c : per_cu_a;
+    // stage A: persistent, two workgroups per CU (what the 64 KiB tiles allow); stage C (reads only) is better off with one
+    // workgroup per item: measured r02, cfg5, per launch of 10.5 rows: 55 us against 61 us persistent (its reads alone run at
+    // 4.1 TB/s either way: 43 us); stage A (mostly stores) gains: 61 -> 52 us
+    const int per_cu = stage_c ? 0 : 2;
     static const int cus = [] {
         int dev = 0, n = 0;
         if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 1) n = 256;
@@ -370,11 +356,10 @@ static hipError_t launch_long_rows_q(hipStream_t s, int n1, int nrows_launch, fl
     if (e != hipSuccess) return e;
     const int items = n1 * nrows_launch;
     static const int qspin = [] { const char *ev = getenv("CRSDR_K1_QSPIN"); return ev ? atoi(ev) : x14p::kQSpinLimit; }();
-    static const int xcdq = [] { const char *ev = getenv("CRSDR_LONG_XCDQ"); return ev ? atoi(ev) : 1; }();      // 0: one queue, lines in memory order
     const int grid = std::max(1, std::min(cus, (items + 1) / 2));
     // one queue per XCD (k_rows14_cf32q); static order: the work counter is not used.  (The apply pass's per-row spectra are
     // 2.7 MB for cfg5 and stay in every L2: lines in memory order there.)
-    const int nq = (!ramp && xcdq && n1 % 8 == 0 && grid % 8 == 0) ? 8 : 1;
+    const int nq = (!ramp && n1 % 8 == 0 && grid % 8 == 0) ? 8 : 1;
     (void)work; (void)work_base;
     hipLaunchKernelGGL(kq, dim3((unsigned)grid), dim3(2 * x14p::QG), x14p::LDSQ_BYTES, s, reinterpret_cast<c2 *>(Y),
                        reinterpret_cast<const c2 *>(twA), reinterpret_cast<const c2 *>(twB), (const float4 *)refspec, n1, nrows_launch, nq, waitflag, qspin,
@@ -385,13 +370,6 @@ static hipError_t launch_long_rows_q(hipStream_t s, int n1, int nrows_launch, fl
 template <bool IS_REF>
 static hipError_t launch_long_rows(hipStream_t s, int n1, int nrows_launch, float2 *Y, const float2 *twA, const float2 *twB, float2 *refspec)
 {
-    if (k1_variant() == 's') {
-        auto kern = x14::k_rows14_cf32<IS_REF>;
-        hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, x14::LDS_BYTES);
-        if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(kern, dim3(n1, nrows_launch), dim3(x14::THREADS), x14::LDS_BYTES, s, Y, twA, twB, (float4 *)refspec);
-        return hipGetLastError();
-    }
     auto kern = x14p::k_rows14_cf32p<IS_REF, false>;
     hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, x14::LDS_BYTES);
     if (e != hipSuccess) return e;
@@ -707,9 +685,8 @@ struct crsdr_plan {
     size_t packet_bytes = 0, matrix_off = 0, packet_stride = 0, own_packet_stride = 0;
     hipStream_t own_stream = nullptr, stream = nullptr, aux = nullptr;
     hipEvent_t ev_fork = nullptr, ev_ref[2] = {nullptr, nullptr}, ev_k1done[2] = {nullptr, nullptr};
-    // K1 on its own stream beside the phase kernel of the previous batch (see crsdr_plan_submit_batch): per-batch
-    // {lag, mag, frac} are double-buffered (obuf), ev_k2done[i] = the phase kernel that read buffer i has finished
-    hipStream_t xs = nullptr;
+    // per-batch {lag, mag, frac} are double-buffered (obuf: a pipelined fetch of batch b reads its buffer while batch b + 1 writes the
+    // other), ev_k2done[i] = the last kernel of the batch that wrote buffer i has finished
     hipStream_t cs = nullptr;                       // copy stream of crsdr_plan_fetch_batch_async
     hipEvent_t ev_copydone[4] = {nullptr, nullptr, nullptr, nullptr};   // one per outstanding asynchronous fetch (ring)
     unsigned long copy_head = 0, copy_tail = 0;      // fetches waited for / issued
@@ -718,7 +695,6 @@ struct crsdr_plan {
     hipEvent_t ev_k2done[2] = {nullptr, nullptr};
     bool k2done_valid[2] = {false, false};
     int obuf = 0;
-    bool overlap = false, last_locked = false;   // overlap: CRSDR_OVERLAP=1 (measured neutral)
     hipEvent_t ev_start = nullptr, ev_stop = nullptr;
     bool k1done_valid[2] = {false, false};
     int slot = 0;
@@ -755,7 +731,7 @@ struct crsdr_plan {
     int snap_head = 0, snap_cnt = 0;
     unsigned long submit_idx = 0;          // batches submitted since create / reset / rollback
     unsigned long copy_idx[4] = {0, 0, 0, 0};   // submit index of the batch each outstanding asynchronous fetch belongs to
-    bool fused_k2 = true, fused_used = false;
+    bool fused_k2 = true, fused_used = false;   // CRSDR_K2_FUSED=0: the three-kernel phase path
     int phase_cur = 0;
     int last_nblocks = 0;
     // long-block path (B > 16384): B = N1 x 16384
@@ -855,12 +831,10 @@ static int plan_alloc(crsdr_plan *p)
     HIP_TRY(hipSetDevice(p->device));
     HIP_TRY(hipStreamCreateWithFlags(&p->own_stream, hipStreamNonBlocking));
     HIP_TRY(hipStreamCreateWithFlags(&p->aux, hipStreamNonBlocking));
-    HIP_TRY(hipStreamCreateWithFlags(&p->xs, hipStreamNonBlocking));
     HIP_TRY(hipStreamCreateWithFlags(&p->cs, hipStreamNonBlocking));
     for (auto &e : p->ev_copydone) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     HIP_TRY(hipHostMalloc((void **)&p->h_k1flag, 4 * sizeof(int), hipHostMallocDefault));
     memset(p->h_k1flag, 0, 4 * sizeof(int));
-    { const char *e = getenv("CRSDR_OVERLAP"); if (e) p->overlap = atoi(e) != 0; }
     p->stream = p->own_stream;
     hipEvent_t *evs[] = {&p->ev_fork, &p->ev_ref[0], &p->ev_ref[1], &p->ev_k1done[0], &p->ev_k1done[1], &p->ev_k2done[0], &p->ev_k2done[1]};
     for (auto e : evs) HIP_TRY(hipEventCreateWithFlags(e, hipEventDisableTiming));
@@ -933,7 +907,6 @@ static void plan_free(crsdr_plan *p)
     (void)hipSetDevice(p->device);
     if (p->own_stream) (void)hipStreamSynchronize(p->own_stream);
     if (p->aux) (void)hipStreamSynchronize(p->aux);
-    if (p->xs) (void)hipStreamSynchronize(p->xs);
     if (p->cs) { (void)hipStreamSynchronize(p->cs); (void)hipStreamDestroy(p->cs); }
     for (auto e : p->ev_copydone) if (e) (void)hipEventDestroy(e);
     void *bufs[] = {p->d_Z, p->d_rowspec, p->d_frac_override, p->d_k2tab, p->d_wc, p->d_wf, p->d_tw1, p->d_Y, p->d_Yref, p->d_part, p->d_tw, p->d_twA, p->d_twB, p->d_refspec[0], p->d_refspec[1], p->d_rows, p->d_packet_alloc, p->d_readcnt,
@@ -948,7 +921,6 @@ static void plan_free(crsdr_plan *p)
     for (hipEvent_t e : p->prof_ev) if (e) (void)hipEventDestroy(e);
     if (p->own_stream) (void)hipStreamDestroy(p->own_stream);
     if (p->aux) (void)hipStreamDestroy(p->aux);
-    if (p->xs) (void)hipStreamDestroy(p->xs);
     delete p;
 }
 
@@ -1001,7 +973,6 @@ extern "C" int crsdr_plan_sync(crsdr_plan *p)
     HIP_TRY(hipSetDevice(p->device));
     HIP_TRY(hipStreamSynchronize(p->stream));
     HIP_TRY(hipStreamSynchronize(p->aux));
-    HIP_TRY(hipStreamSynchronize(p->xs));
     HIP_TRY(hipStreamSynchronize(p->cs));
     p->copy_pending = false;
     p->copy_head = p->copy_tail;
@@ -1228,7 +1199,6 @@ extern "C" int crsdr_plan_submit_batch(crsdr_plan *p, const void *rows, int mem_
         // input copies above stay ahead of this wait, so they share the link with the device-to-host copies
         hipEvent_t newest = p->ev_copydone[(p->copy_tail - 1) % 4];
         HIP_TRY(hipStreamWaitEvent(S, newest, 0));
-        if (p->overlap) HIP_TRY(hipStreamWaitEvent(p->xs, newest, 0));
         p->copy_pending = false;
     }
     if (p->prof_slots) {
@@ -1251,8 +1221,7 @@ extern "C" int crsdr_plan_submit_batch(crsdr_plan *p, const void *rows, int mem_
     aa.xcorr_ran = any_lag ? 1 : 0;
     aa.inline_chain = 0;
     // rows in and packet rows out are touched once: non-temporal (measured in the locked cadence, A/B in one call: stores +2.3 %, loads neutral)
-    static const int k2_nt = [] { const char *e = getenv("CRSDR_K2_NT"); return e ? atoi(e) : 3; }();
-    aa.nt = k2_nt;
+    aa.nt = 3;
     aa.seq = seq; aa.xor80 = xor80;
     aa.slab = p->d_slab; aa.slab_stride = p->slab_stride; aa.hdr_first = p->hdr_first; aa.hdr_count = p->hdr_count;
     aa.lag_out = o_lag; aa.mag_out = o_mag; aa.frac_out = o_frac; aa.mag_state = p->d_mag_state; aa.frac_state = p->d_frac_state;
@@ -1264,20 +1233,11 @@ extern "C" int crsdr_plan_submit_batch(crsdr_plan *p, const void *rows, int mem_
                        (!p->d_slab || ((uintptr_t)p->d_slab % 16 == 0 && p->slab_stride % 16 == 0));
     const int chunks = p->B > 16384 ? p->B / 16384 : 1; // long rows: 16 KiB of the row per workgroup
     const bool fused = p->fused_k2 && vec16 && chunks == 1;
-    // Optional stream layout of a batch (CRSDR_OVERLAP=1; B <= 16384, fused phase kernel):
-    //   aux: K0(b)        X: K1(b)        S: phase kernel(b)
-    // K1 leaves 112 VGPRs per SIMD and 28 KiB of LDS unused and the phase kernel is HBM bound and small in registers, so
-    // with K1 of batch b+1 on its own stream the two do share the CUs.  What makes that legal: per-batch {lag, mag,
-    // frac} are double-buffered (K1(b+1) writes the other buffer; K1(b+2) waits for the phase kernel of batch b), the
-    // carried lag / mag / frac state is only touched on X (the phase kernel reads the per-batch arrays, into which K1
-    // republishes the state of rows that were not requested), and a batch without cross-correlation, which does read
-    // the state on S, is waited for by the next K1.  Measured: throughput unchanged (16.1 k blocks/s either way) -- K1
-    // stretches by exactly what the phase kernel costs alone (0.83 -> 0.96 ms per launch): extra waves take issue
-    // slots from K1's two waves per SIMD rather than filling their stalls.  Off by default.
-    const bool use_x = p->overlap && fused && any_lag && !p->longblock;
+    // (K1 of batch b + 1 on its own stream beside the phase kernel of batch b was built and measured in r01 / r02 -- dead ends 5 and 10
+    // of DESIGN.md: the kernels do overlap, and K1 stretches by exactly what the phase kernel costs alone -- and removed in r03.)
     bool corr_zeroed = false;
     bool kept_fwd = false;                        // long blocks: stage A's output survived the correlation pass (in d_Y; stage B wrote d_Z)
-    hipStream_t KS = use_x ? p->xs : S;
+    hipStream_t KS = S;
 
     if (any_lag && p->longblock) {
         // B = N1 x 16384: column FFTs -> row FFTs (x conj ref, inverse) -> inverse column FFTs + argmax -> finalize
@@ -1364,16 +1324,10 @@ extern "C" int crsdr_plan_submit_batch(crsdr_plan *p, const void *rows, int mem_
         XcorrArgs xa;
         xa.rows = d_in; xa.block_stride = d_stride; xa.refspec = p->d_refspec[slot]; xa.lag_mask = d_mask;
         xa.row_begin = p->row_begin; xa.nrows = p->nrows; xa.nblocks = nblocks; xa.xor80 = xor80;
-        static const int stagger = [] { const char *sg = getenv("CRSDR_K1_STAGGER"); return sg ? atoi(sg) : 0; }();
-        xa.stagger = stagger; // x 512 cycles; 0 is best for the packed kernel, 1 for the scalar one
+        xa.stagger = 0;       // (x 512 cycles of head start for half the waves: measured r01, 0 is best for the packed kernels)
         xa.lag = o_lag; xa.mag = o_mag; xa.frac = o_frac;
         xa.lag_state = p->d_lag_state; xa.mag_state = p->d_mag_state; xa.frac_state = p->d_frac_state;
         HIP_TRY(hipStreamWaitEvent(KS, p->ev_ref[slot], 0));
-        if (use_x) {
-            if (forked) HIP_TRY(hipStreamWaitEvent(KS, p->ev_fork, 0));
-            if (p->k2done_valid[obuf]) HIP_TRY(hipStreamWaitEvent(KS, p->ev_k2done[obuf], 0));            // lag[obuf] free again
-            if (p->last_locked && p->k2done_valid[obuf ^ 1]) HIP_TRY(hipStreamWaitEvent(KS, p->ev_k2done[obuf ^ 1], 0)); // it read the state
-        }
         hipEvent_t *pe1 = prof_pair(p, CRSDR_KERNEL_XCORR_LAG);
         if (pe1) HIP_TRY(hipEventRecord(pe1[0], KS));
         if (p->log2n == 14) {
@@ -1381,18 +1335,15 @@ extern "C" int crsdr_plan_submit_batch(crsdr_plan *p, const void *rows, int mem_
             // every two-row launch snapshots the carried state first (one 28 B/row copy, ordered after the previous batch's
             // kernels on this stream) while the ring has room: what a wait that ran out is rolled back to
             auto snapshot = [p, KS]() -> hipError_t { return take_snapshot(p, KS); };
-            // (with K1 on its own stream the phase kernel of the previous batch may still be writing the state: packed kernel there)
             HIP_TRY(launch_xcorr_lag14(KS, xa, p->row_count, p->d_twA, p->d_twB, reinterpret_cast<int *>(p->d_sync + 2), &q, p->d_sync + 3, &p->q_work_base,
-                                       !p->q_disabled && !use_x, snapshot));
+                                       !p->q_disabled, snapshot));
             p->k1_used |= q;
         }
         else HIP_TRY(CRSDR_DISPATCH_LOG2(p->log2n, (launch_xcorr_lag<LG>(KS, xa, p->row_count, p->d_tw))));
         if (pe1) HIP_TRY(hipEventRecord(pe1[1], KS));
         HIP_TRY(hipEventRecord(p->ev_k1done[slot], KS));
         p->k1done_valid[slot] = true;
-        if (use_x) HIP_TRY(hipStreamWaitEvent(S, p->ev_k1done[slot], 0));
     }
-    // (a batch that runs entirely on S needs no extra wait: every earlier K1 on X was awaited by its own phase kernel on S)
     if (fused) {
         // fused phase path: every row is read once (k_align_fused); timed under CRSDR_KERNEL_ALIGN_QUANT
         static const int spin_limit = [] { const char *e = getenv("CRSDR_K2_SPIN"); return e ? atoi(e) : kFusedSpinLimit; }();
@@ -1416,6 +1367,7 @@ extern "C" int crsdr_plan_submit_batch(crsdr_plan *p, const void *rows, int mem_
             p->chain_slot = cs ^ 1;
         }
         {
+            // (two rows per workgroup sharing the reference row's registers: built and measured in r03, 4.05 against 4.85 TB/s -- tools/k2_pair.hpp)
             const dim3 grid((unsigned)((1 + p->row_count) * nblocks));
             if (p->B == 16384 && !xor80) hipLaunchKernelGGL((k_align_fused<true, false>), grid, dim3(kAlignThreads), 0, S, aa, fs);
             else if (p->B == 16384) hipLaunchKernelGGL((k_align_fused<true, true>), grid, dim3(kAlignThreads), 0, S, aa, fs);
@@ -1426,7 +1378,6 @@ extern "C" int crsdr_plan_submit_batch(crsdr_plan *p, const void *rows, int mem_
         { int rc_ = pack_tails(p, S, nblocks, o_lag, o_mag, o_frac); if (rc_) return rc_; }
         HIP_TRY(hipEventRecord(p->ev_k2done[obuf], S));
         p->k2done_valid[obuf] = true;
-        p->last_locked = !any_lag;
         p->fused_used = true;
         p->phase_cur = pout;
         p->last_nblocks = nblocks;
@@ -1493,7 +1444,6 @@ extern "C" int crsdr_plan_submit_batch(crsdr_plan *p, const void *rows, int mem_
     { int rc_ = pack_tails(p, S, nblocks, o_lag, o_mag, o_frac); if (rc_) return rc_; }
     HIP_TRY(hipEventRecord(p->ev_k2done[obuf], S));
     p->k2done_valid[obuf] = true;
-    p->last_locked = !any_lag;
     p->phase_cur = pout;
     p->last_nblocks = nblocks;
     if (p->prof_slots) { if (p->prof_mask & (1u << 31)) HIP_TRY(hipEventRecord(p->ev_stop, S)); p->prof_count++; }
@@ -1508,8 +1458,8 @@ extern "C" int crsdr_plan_submit(crsdr_plan *p, const void *rows, int mem_kind, 
     return crsdr_plan_submit_batch(p, rows, mem_kind, 1, 0, readcnt, lag_mask, seq, flags);
 }
 
-// the fused phase kernel counts look-back waits it gave up on (and computed locally): nothing to report, results are
-// exact either way; the counter is only kept for diagnostics (CRSDR_K2_DEBUG=1 prints it)
+// (the fused phase kernel counts look-back waits it gave up on and computed locally -- d_sync[1] -- : nothing to report, results
+// are exact either way)
 static int check_fused_status(crsdr_plan *p)
 {
     // the two-row K1 (xcorr14q.hpp) bounds its waits for the LDS image and its group barriers; one that runs out means a
@@ -1522,7 +1472,7 @@ static int check_fused_status(crsdr_plan *p)
             // lag / mag / frac and EMA phase state.  Restore the snapshot taken before the first of them, re-arm the
             // phase kernel's hand-over words, and keep this plan on the packed kernel from here on -- the caller
             // resubmits those batches and gets what an undisturbed run would have given.
-            (void)hipStreamSynchronize(p->stream); (void)hipStreamSynchronize(p->aux); (void)hipStreamSynchronize(p->xs); (void)hipStreamSynchronize(p->cs);
+            (void)hipStreamSynchronize(p->stream); (void)hipStreamSynchronize(p->aux); (void)hipStreamSynchronize(p->cs);
             (void)hipMemset(p->d_sync, 0, 64);                    // flags and the work counter (its count is off after a failed launch)
             p->q_work_base = 0;
             unsigned long lost = 0;
@@ -1543,11 +1493,6 @@ static int check_fused_status(crsdr_plan *p)
         }
         p->snap_cnt = 0; p->snap_head = 0; p->k1_used = false;      // clean and the streams are drained: the next two-row launch takes a fresh snapshot
     }
-    static const bool dbg = [] { const char *e = getenv("CRSDR_K2_DEBUG"); return e && atoi(e) != 0; }();
-    if (!p->fused_used || !dbg) return CRSDR_OK;
-    unsigned int st = 0;
-    HIP_TRY(hipMemcpy(&st, p->d_sync + 1, sizeof(st), hipMemcpyDeviceToHost));
-    if (st) { std::fprintf(stderr, "crsdr: fused phase kernel computed %u look-back values locally\n", st); (void)hipMemset(p->d_sync, 0, 8); }
     return CRSDR_OK;
 }
 

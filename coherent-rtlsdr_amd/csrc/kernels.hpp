@@ -560,9 +560,7 @@ constexpr int kFusedSpinLimit = 2048;      // polls of ~1 us each before a workg
 // FULL: B == 16384, every thread owns exactly four 16-byte vectors of the row (no bounds checks in the hot loops)
 // XOR: the input is offset binary (CRSDR_OFFSET_BINARY); false folds the 40-odd "^ xor80" of a thread away (5 % of its VALU work)
 template <bool FULL, bool XOR>
-// amdgpu_waves_per_eu(8, 8): eight waves per SIMD is what 59 VGPRs give; told so, the compiler keeps its ~96 scalar registers instead of
-// squeezing into the 80 a tenth wave would need (which no VGPR budget here allows) and spilling 18 - 41 of them through v_writelane / v_readlane
-__global__ __launch_bounds__(kAlignThreads) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_align_fused(AlignArgs a_, FusedSync fs)
+__global__ __launch_bounds__(kAlignThreads, 8) void k_align_fused(AlignArgs a_, FusedSync fs)
 {
     AlignArgs a = a_;
     a.xor80 = XOR ? a_.xor80 : 0u;                 // a compile-time zero without XOR
