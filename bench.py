@@ -83,8 +83,14 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    # CRSDR_BENCH_FORCE_EXCHANGE=1 (one process): the N > 1 code path with a process group of ONE rank -- slots, the all-to-all
+    # (to itself), the assembly on the side stream, the three ring-buffered sets -- to read its host cost per batch and its
+    # stream ordering off a one-GPU box before the driver's node runs it with real peers
+    force_x = world == 1 and os.environ.get("CRSDR_BENCH_FORCE_EXCHANGE") == "1"
+    multi = world > 1 or force_x
+    if multi:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         if rehearsal:
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
@@ -108,7 +114,7 @@ def main():
         T = max(1, args.steps)
     else:
         T = 64 if world == 1 else max(world, 64 // world * world)
-    nbuf = max(2 * T if world > 1 else T, (args.nbuf // T) * T)   # whole batches, contiguous in HBM
+    nbuf = max(2 * T if multi else T, (args.nbuf // T) * T)   # whole batches, contiguous in HBM
     seed = synth.config_seed(4)
     params = synth.RowParams(nsig, L, seed)
     d_in = torch.empty((nbuf, nrows, B), dtype=torch.uint8, device=dev)
@@ -135,14 +141,14 @@ def main():
     # of every packet is 16-byte aligned.  One GPU: T packets per set.  Several GPUs: per set one slot buffer
     # [T][slot_stride] (rows + the 20 B/row {lag, mag, frac, phasor} tail of the rank's slab: the all-to-all's send side),
     # one receive buffer [G][Tg][slot_stride], the Tg = ceil(T/G) packets this rank assembles and their scalars blocks.
-    NSETS = 3 if world > 1 else 2
+    NSETS = 3 if multi else 2
     Tg = -(-T // world)
     pstride = (plan.packet_bytes + 255) // 256 * 256
     packets = [torch.zeros(pstride * Tg + 64, dtype=torch.uint8, device=dev) for _ in range(NSETS)]
     pk_off = [(-(p.data_ptr() + plan.matrix_offset)) % 16 for p in packets]
     pk_view = [[p[o + t * pstride: o + t * pstride + plan.packet_bytes] for t in range(Tg)] for p, o in zip(packets, pk_off)]
     flags = b.REFNOISE_ENABLED | b.INPUT_READY
-    if world > 1:
+    if multi:
         geo = b.exchange_geometry(nrows, B, world)
         slot, toff, sstride = geo["slot_stride"], geo["tail_offset"], geo["scalars_stride"]
         send = [torch.zeros(T * slot, dtype=torch.uint8, device=dev) for _ in range(NSETS)]
@@ -163,7 +169,7 @@ def main():
             gib["last_full"] = ib
         k = ib % NSETS
         first_buf = (ib * T) % nbuf
-        if world == 1:
+        if not multi:
             plan.bind_packet(pk_view[k][0].data_ptr(), pstride)
             plan.submit(d_in[first_buf].data_ptr(), seq=ib * T, flags=fl, nblocks=nb, block_stride=block_bytes)
             return
@@ -228,7 +234,7 @@ def main():
         for _ in range(regions):
             run_steps(nsteps, fl)
         t_issue = time.perf_counter() - t0              # host time to enqueue everything (no waiting on the GPU)
-        if world > 1:
+        if multi:
             for ev in done:
                 if ev is not None:
                     stream.wait_event(ev)               # this rank's outstanding exchanges + assemblies
@@ -249,7 +255,7 @@ def main():
     # communicator set-up (not a step): RCCL opens its point-to-point channels lazily, on the first exchange
     # between each rank pair -- do that here, on the still-empty buffers, so that connection set-up cannot land
     # inside the timed region whatever the warm-up length is
-    if world > 1 and not rehearsal:
+    if multi and not rehearsal:
         sharding.exchange_slots(recv[NSETS - 1], send[NSETS - 1], T, slot, async_op=False)
         torch.cuda.synchronize()
         dist.barrier()
@@ -280,7 +286,7 @@ def main():
     # checked right here, before later (untimed) runs reuse the packet sets: the last full batch -- every packet this rank
     # assembled must hold every rank's rows under the header of the right block, and its scalars block every rank's lags
     assembled_ok = scalars_ok = True
-    if world > 1:
+    if multi:
         torch.cuda.synchronize()
         if gib["last_full"] is not None and gib["n"] - gib["last_full"] <= NSETS:
             ib = gib["last_full"]                    # the series' last full batch: its output set has not been reused (fewer than NSETS batches after it)
@@ -356,6 +362,7 @@ def main():
                                    f"(FFT xcorr every block), {args.mode} mode, inputs resident in HBM, "
                                    f"{nbuf} rotating input blocks, {T} blocks per submit",
                        "rows": nrows, "L": L, "fft_len": B, "mode": args.mode, "batch": T,
+                       "forced_exchange_path": force_x,
                        "parallelism": f"rows sharded x{world}, ref replicated, rotating-root gather of int8 rows + 20 B/row {{lag, mag, frac, phasor}}: one RCCL all-to-all per {T}-block batch + local assembly, overlapped with the next batch" if world > 1 else "single GPU"},
             "roofline": {"bound": "hbm", "kernel": "k_xcorr_lag", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": _committed_traffic("k_xcorr_lag", tb)[0],
@@ -371,7 +378,7 @@ def main():
             "host_issue_ms_per_batch": host_ms_per_batch,
             "k0": {"launch_ms": float(np.mean(k_ms["ref_spectrum"])) if len(k_ms["ref_spectrum"]) else None, "cold_batch": cold,
                    "note": "K0 runs on the aux stream under the previous batch; cold_batch = one batch with nothing in flight before it"},
-            "lags_exact": lags_ok, "matrix_assembled": assembled_ok if world > 1 else None, "scalars_assembled": scalars_ok if world > 1 else None,
+            "lags_exact": lags_ok, "matrix_assembled": assembled_ok if multi else None, "scalars_assembled": scalars_ok if multi else None,
             "env": _env(torch, dev, b, local_rank),
         }
 
@@ -536,7 +543,7 @@ def main():
             sys.exit(4)
 
     plan.close()
-    if world > 1:
+    if multi:
         dist.destroy_process_group()
 
 
