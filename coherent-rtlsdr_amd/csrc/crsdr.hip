@@ -245,26 +245,39 @@ static hipError_t launch_ref_spectrum14(hipStream_t s, int nblocks, const int8_t
     return hipGetLastError();
 }
 
-static hipError_t launch_xcorr_lag14(hipStream_t s, const XcorrArgs &a, int row_count, const float2 *twA, const float2 *twB, int *waitflag, bool *used_q,
-                                     unsigned int *work, unsigned int *work_base, bool allow_q, const std::function<hipError_t()> &before_q)
+static int device_cus()
 {
     static const int cus = [] {
         int dev = 0, n = 0;
         if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 1) n = 256;
         return n;
     }();
-    const int items = row_count * a.nblocks;
+    return cus;
+}
+// which B = 16384 cross-correlation kernel a launch of rows_all rows takes: 'q' (two rows per CU) or 'p' (one)
+static char k1_pick(int rows_all, bool allow_q)
+{
     char variant = k1_variant();
     // measured (r01, T = 64): q is 3-7 % faster at 1024 / 256 / 128 / 96 / 48 rows per block (256 ... 12 rows per CU and launch),
-    // 1.4 % at 64, level with p at 32 and 21 rows (8 and 5 per CU)
-    if (variant == 'a') variant = items >= 12 * cus ? 'q' : 'p';
+    // 1.4 % at 64, level with p at 32 and 21 rows (8 and 5 per CU; r03: level at 10 as well)
+    if (variant == 'a') variant = rows_all >= 12 * device_cus() ? 'q' : 'p';
     if (variant == 'q' && !allow_q) variant = 'p';   // a plan whose two-row kernel once ran out of a bounded wait stays on the packed kernel
+    return variant;
+}
+static hipError_t launch_xcorr_lag14(hipStream_t s, const XcorrArgs &a, int row_count, const float2 *twA, const float2 *twB, int *waitflag, bool *used_q,
+                                     unsigned int *work, unsigned int *work_base, bool allow_q, const std::function<hipError_t()> &before_bounded)
+{
+    const int cus = device_cus();
+    const int rows_all = row_count * a.nblocks, items = rows_all + (a.fold ? a.nblocks : 0);
+    const char variant = k1_pick(rows_all, allow_q);
     if (used_q) *used_q = variant == 'q';
+    // a launch with bounded waits (the two-row kernel's, a folded launch's wait for its reference spectra) snapshots the carried state first
+    if ((variant == 'q' || a.fold) && before_bounded) { hipError_t eb = before_bounded(); if (eb != hipSuccess) return eb; }
     if (variant != 'q') {
         auto kp = x14p::k_xcorr_lag14p;
         hipError_t ep = hipFuncSetAttribute((const void *)kp, hipFuncAttributeMaxDynamicSharedMemorySize, x14::LDS_BYTES);
         if (ep != hipSuccess) return ep;
-        hipLaunchKernelGGL(kp, dim3(row_count, a.nblocks), dim3(x14::THREADS), x14::LDS_BYTES, s, a, twA, twB);
+        hipLaunchKernelGGL(kp, dim3((unsigned)items), dim3(x14::THREADS), x14::LDS_BYTES, s, a, twA, twB, row_count);
         return hipGetLastError();
     }
     {   // two rows per CU in opposite phases (xcorr14q.hpp), one persistent workgroup per CU
@@ -276,7 +289,6 @@ static hipError_t launch_xcorr_lag14(hipStream_t s, const XcorrArgs &a, int row_
         static const long qspin_from = [] { const char *e = getenv("CRSDR_K1_QSPIN"); const char *at = e ? strchr(e, '@') : nullptr; return at ? atol(at + 1) : 0L; }();
         static long qlaunches = 0;
         const int qspin = qlaunches++ >= qspin_from ? qspin_env : x14p::kQSpinLimit;
-        if (before_q) { hipError_t eb = before_q(); if (eb != hipSuccess) return eb; }   // snapshot of the carried state (rollback on a wait that ran out)
         hipLaunchKernelGGL(kq, dim3((unsigned)std::max(1, std::min(cus, (items + 1) / 2))), dim3(2 * x14p::QG), x14p::LDSQ_BYTES, s, a, twA, twB, row_count,
                            waitflag, work, *work_base, qspin);
         const hipError_t el = hipGetLastError();
@@ -356,7 +368,17 @@ static hipError_t launch_long_rows_q(hipStream_t s, int n1, int nrows_launch, fl
     if (e != hipSuccess) return e;
     const int items = n1 * nrows_launch;
     static const int qspin = [] { const char *ev = getenv("CRSDR_K1_QSPIN"); return ev ? atoi(ev) : x14p::kQSpinLimit; }();
-    const int grid = std::max(1, std::min(cus, (items + 1) / 2));
+    // Whole rounds: a launch of `items` lines takes ceil(items / (2 cus)) rounds of two lines per CU, and the stage is bound by the bytes
+    // it moves, not by CUs -- so the lines are dealt to just as many workgroups as make every round full (cfg5: 2688 lines = 6 rounds
+    // x 448 groups on 224 CUs, instead of 5 full rounds on 256 CUs and a sixth with 128 lines on 128 CUs at a quarter of the bandwidth)
+    static const int balance = [] { const char *ev = getenv("CRSDR_LONG_BALANCE"); return ev ? atoi(ev) : 1; }();
+    const int rounds = std::max(1, (items + 2 * cus - 1) / (2 * cus));
+    int grid = std::max(1, std::min(cus, (items + 1) / 2));
+    if (balance && items > 2 * cus) {
+        int gbal = (items + 2 * rounds - 1) / (2 * rounds);
+        gbal = (gbal + 7) / 8 * 8;                               // whole XCD octets (the per-XCD queues below)
+        if (gbal <= cus) grid = gbal;
+    }
     // one queue per XCD (k_rows14_cf32q); static order: the work counter is not used.  (The apply pass's per-row spectra are
     // 2.7 MB for cfg5 and stay in every L2: lines in memory order there.)
     const int nq = (!ramp && n1 % 8 == 0 && grid % 8 == 0) ? 8 : 1;
@@ -732,6 +754,10 @@ struct crsdr_plan {
     unsigned long submit_idx = 0;          // batches submitted since create / reset / rollback
     unsigned long copy_idx[4] = {0, 0, 0, 0};   // submit index of the batch each outstanding asynchronous fetch belongs to
     bool fused_k2 = true, fused_used = false;   // CRSDR_K2_FUSED=0: the three-kernel phase path
+    // B = 16384: the blocks' reference spectra as the first work items of the cross-correlation launch itself (CRSDR_K1_FOLD=0: from
+    // k_ref_spectrum14p on the aux stream, two cross-stream dependencies and an event record per batch more)
+    bool fold = true;
+    unsigned int *d_refflag = nullptr, refgen = 0;     // [max_batch] words: the launch generation whose spectrum of block t is in place
     int phase_cur = 0;
     int last_nblocks = 0;
     // long-block path (B > 16384): B = N1 x 16384
@@ -883,6 +909,9 @@ static int plan_alloc(crsdr_plan *p)
     HIP_TRY(hipMalloc((void **)&p->d_corr, sizeof(long long) * 4 * n * T));   // unit words, then chain values (k_align_fused)
     HIP_TRY(hipMalloc((void **)&p->d_sync, 64));
     HIP_TRY(hipMemset(p->d_sync, 0, 64));
+    HIP_TRY(hipMalloc((void **)&p->d_refflag, sizeof(unsigned int) * T));
+    HIP_TRY(hipMemset(p->d_refflag, 0, sizeof(unsigned int) * T));
+    { const char *e = getenv("CRSDR_K1_FOLD"); if (e) p->fold = atoi(e) != 0; }
     { const char *e = getenv("CRSDR_K2_FUSED"); if (e) p->fused_k2 = atoi(e) != 0; }
     {
         const size_t n8 = (n + 1) / 2 * 2;                   // keeps the float2 arrays 8-byte aligned
@@ -910,7 +939,7 @@ static void plan_free(crsdr_plan *p)
     if (p->cs) { (void)hipStreamSynchronize(p->cs); (void)hipStreamDestroy(p->cs); }
     for (auto e : p->ev_copydone) if (e) (void)hipEventDestroy(e);
     void *bufs[] = {p->d_Z, p->d_rowspec, p->d_frac_override, p->d_k2tab, p->d_wc, p->d_wf, p->d_tw1, p->d_Y, p->d_Yref, p->d_part, p->d_tw, p->d_twA, p->d_twB, p->d_refspec[0], p->d_refspec[1], p->d_rows, p->d_packet_alloc, p->d_readcnt,
-                    p->d_mask, p->d_lag, p->d_mag, p->d_frac, p->d_phasor, p->d_corr, p->d_sync, p->d_state, p->d_state_snap};
+                    p->d_mask, p->d_lag, p->d_mag, p->d_frac, p->d_phasor, p->d_corr, p->d_sync, p->d_state, p->d_state_snap, p->d_refflag};
     for (void *b : bufs) if (b) (void)hipFree(b);
     if (p->h_k1flag) (void)hipHostFree(p->h_k1flag);
     if (p->h_readcnt) (void)hipHostFree(p->h_readcnt);
@@ -1305,21 +1334,33 @@ extern "C" int crsdr_plan_submit_batch(crsdr_plan *p, const void *rows, int mem_
         if (pe1) HIP_TRY(hipEventRecord(pe1[1], S));
     } else if (any_lag) {
         const int slot = (p->slot ^= 1);
-        // K0 on the aux stream: with resident input it overlaps the previous batch's K1 / K2.  (Putting it on the main stream
-        // when both streams are idle -- a cold batch -- was measured in r02: exposed K0 0.0526 -> 0.0516 ms per cold batch and
-        // no difference beyond the spread in a 20-block timed region; not kept.)
-        const bool forked = !input_ready || d_readcnt || d_mask;
-        if (forked) {
-            HIP_TRY(hipEventRecord(p->ev_fork, S)); // input copies, mask copy / the caller's producer work
-            if (!input_ready) HIP_TRY(hipStreamWaitEvent(A, p->ev_fork, 0));
+        // B = 16384: the reference spectra are the first work items of the cross-correlation launch itself (fold) -- one launch, no
+        // second stream, no event between the launches of a batch.  r03, per-rank shape of the 8-GPU run (128 rows x 20 blocks,
+        // 0.16 ms per batch): the kernel on the aux stream could only start when the previous batch's K1 let go of its CUs, and the
+        // cross-stream wait + the event record between K1 and the phase kernel left 11 + 11 us of gaps around 138 us of kernels.
+        // Folded where the launch is small (the packed kernel's launches: a GPU's share of an 8-GPU run, 0.16 ms per batch): K1 itself
+        // grows by the reference items and its first rows' wait for them (0.118 -> 0.129 ms per 2560-row launch), the gaps around it
+        // shrink by more (fenced 110 k -> 117 k blocks/s, back to back 122.9 k -> 124.6 k) and the host issues a batch in 10 us
+        // instead of 26 - 40.  The two-row kernel's large launches keep the aux-stream kernel: there it hides completely, and the
+        // folded form measured 0.910 -> 0.932 ms per 20-block launch of 1024 rows (every group's first row waits for block 0's item).
+        const bool fold = p->fold && p->log2n == 14 && !p->q_disabled && k1_pick(p->row_count * nblocks, !p->q_disabled) == 'p';
+        if (!fold) {
+            // K0 on the aux stream: with resident input it overlaps the previous batch's K1 / K2.  (Putting it on the main stream
+            // when both streams are idle -- a cold batch -- was measured in r02: exposed K0 0.0526 -> 0.0516 ms per cold batch and
+            // no difference beyond the spread in a 20-block timed region; not kept.)
+            const bool forked = !input_ready || d_readcnt || d_mask;
+            if (forked) {
+                HIP_TRY(hipEventRecord(p->ev_fork, S)); // input copies, mask copy / the caller's producer work
+                if (!input_ready) HIP_TRY(hipStreamWaitEvent(A, p->ev_fork, 0));
+            }
+            if (p->k1done_valid[slot]) HIP_TRY(hipStreamWaitEvent(A, p->ev_k1done[slot], 0)); // refspec[slot] free again
+            hipEvent_t *pe0 = prof_pair(p, CRSDR_KERNEL_REF_SPECTRUM);
+            if (pe0) HIP_TRY(hipEventRecord(pe0[0], A));
+            if (p->log2n == 14) HIP_TRY(launch_ref_spectrum14(A, nblocks, d_in, d_stride, p->d_twA, p->d_twB, p->d_refspec[slot], xor80));
+            else HIP_TRY(CRSDR_DISPATCH_LOG2(p->log2n, (launch_ref_spectrum<LG>(A, nblocks, d_in, d_stride, p->d_tw, p->d_refspec[slot], xor80))));
+            if (pe0) HIP_TRY(hipEventRecord(pe0[1], A));
+            HIP_TRY(hipEventRecord(p->ev_ref[slot], A));
         }
-        if (p->k1done_valid[slot]) HIP_TRY(hipStreamWaitEvent(A, p->ev_k1done[slot], 0)); // refspec[slot] free again
-        hipEvent_t *pe0 = prof_pair(p, CRSDR_KERNEL_REF_SPECTRUM);
-        if (pe0) HIP_TRY(hipEventRecord(pe0[0], A));
-        if (p->log2n == 14) HIP_TRY(launch_ref_spectrum14(A, nblocks, d_in, d_stride, p->d_twA, p->d_twB, p->d_refspec[slot], xor80));
-        else HIP_TRY(CRSDR_DISPATCH_LOG2(p->log2n, (launch_ref_spectrum<LG>(A, nblocks, d_in, d_stride, p->d_tw, p->d_refspec[slot], xor80))));
-        if (pe0) HIP_TRY(hipEventRecord(pe0[1], A));
-        HIP_TRY(hipEventRecord(p->ev_ref[slot], A));
 
         XcorrArgs xa;
         xa.rows = d_in; xa.block_stride = d_stride; xa.refspec = p->d_refspec[slot]; xa.lag_mask = d_mask;
@@ -1327,22 +1368,28 @@ extern "C" int crsdr_plan_submit_batch(crsdr_plan *p, const void *rows, int mem_
         xa.stagger = 0;       // (x 512 cycles of head start for half the waves: measured r01, 0 is best for the packed kernels)
         xa.lag = o_lag; xa.mag = o_mag; xa.frac = o_frac;
         xa.lag_state = p->d_lag_state; xa.mag_state = p->d_mag_state; xa.frac_state = p->d_frac_state;
-        HIP_TRY(hipStreamWaitEvent(KS, p->ev_ref[slot], 0));
+        if (fold) {
+            xa.fold = 1; xa.refspec_w = p->d_refspec[slot]; xa.refflag = p->d_refflag; xa.refgen = ++p->refgen;
+            xa.errflag = reinterpret_cast<int *>(p->d_sync + 2);
+        } else
+            HIP_TRY(hipStreamWaitEvent(KS, p->ev_ref[slot], 0));
         hipEvent_t *pe1 = prof_pair(p, CRSDR_KERNEL_XCORR_LAG);
         if (pe1) HIP_TRY(hipEventRecord(pe1[0], KS));
         if (p->log2n == 14) {
             bool q = false;
-            // every two-row launch snapshots the carried state first (one 28 B/row copy, ordered after the previous batch's
-            // kernels on this stream) while the ring has room: what a wait that ran out is rolled back to
+            // every launch with bounded waits snapshots the carried state first (one 28 B/row copy, ordered after the previous
+            // batch's kernels on this stream) while the ring has room: what a wait that ran out is rolled back to
             auto snapshot = [p, KS]() -> hipError_t { return take_snapshot(p, KS); };
             HIP_TRY(launch_xcorr_lag14(KS, xa, p->row_count, p->d_twA, p->d_twB, reinterpret_cast<int *>(p->d_sync + 2), &q, p->d_sync + 3, &p->q_work_base,
                                        !p->q_disabled, snapshot));
-            p->k1_used |= q;
+            p->k1_used |= q || fold;
         }
         else HIP_TRY(CRSDR_DISPATCH_LOG2(p->log2n, (launch_xcorr_lag<LG>(KS, xa, p->row_count, p->d_tw))));
         if (pe1) HIP_TRY(hipEventRecord(pe1[1], KS));
-        HIP_TRY(hipEventRecord(p->ev_k1done[slot], KS));
-        p->k1done_valid[slot] = true;
+        if (!fold) {                                     // (a folded launch's spectra are written and read on this stream only)
+            HIP_TRY(hipEventRecord(p->ev_k1done[slot], KS));
+            p->k1done_valid[slot] = true;
+        }
     }
     if (fused) {
         // fused phase path: every row is read once (k_align_fused); timed under CRSDR_KERNEL_ALIGN_QUANT

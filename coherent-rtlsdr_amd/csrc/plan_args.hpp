@@ -17,7 +17,40 @@ struct XcorrArgs {
     float *mag, *frac;
     int32_t *lag_state;     // [nrows] last known lag per row (carried across batches)
     float *mag_state, *frac_state;
+    // B = 16384 kernels with the reference spectra folded in (fold = 1): the launch's first work items / workgroups transform the
+    // blocks' reference rows themselves (what k_ref_spectrum14p does on the aux stream otherwise), store conj(spectrum) through
+    // refspec_w and publish refflag[t] = refgen; a signal row of block t waits for that word before it reads the spectrum.
+    int fold = 0;
+    float2 *refspec_w = nullptr;
+    unsigned int *refflag = nullptr;   // [T] device words, monotonic: refgen of the last launch that published block t's spectrum
+    unsigned int refgen = 0;
+    int *errflag = nullptr;            // a bounded wait ran out (the two-row kernel's word: the host rolls the plan back)
 };
+
+// wave-level wait for a published word (every lane leaves with the same verdict); false = the poll budget ran out.
+// `early` is what the wave's first lane read from the word at the START of its row (word_peek): a load whose latency has long
+// been paid by the time the row needs the verdict -- only the first rows of a launch ever find the word not yet there and poll.
+__device__ __forceinline__ unsigned int word_peek(const unsigned int *word)
+{
+    unsigned int v = 0u;
+    if ((threadIdx.x & 63) == 0) v = __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return v;
+}
+__device__ __forceinline__ bool wait_word(const unsigned int *word, unsigned int want, unsigned int early, int budget)
+{
+    unsigned int v = (unsigned int)__builtin_amdgcn_readfirstlane((int)early);
+    int spins = 0;
+    while (v != want) {
+        if (++spins > budget) return false;
+        __builtin_amdgcn_s_sleep(16);      // ~0.5 us between polls: one poller per workgroup, and it must not crowd the publisher's own traffic out of the word's L2 channel
+        unsigned int w = want;
+        if ((threadIdx.x & 63) == 0) w = __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        v = (unsigned int)__builtin_amdgcn_readfirstlane((int)w);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");      // what the publisher stored before the word is visible to this wave's loads
+    return true;
+}
+constexpr int kRefWaitBudget = 1 << 20;      // polls of >= 0.3 us: a reference item takes ~10 us, this is a third of a second
 
 // A row that did not request a lag keeps its previous lag/mag/frac (src/ccoherent.cc:266: only
 // is_lagrequested() devices are queued): the workgroup just republishes the state and leaves.

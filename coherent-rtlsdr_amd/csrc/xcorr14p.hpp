@@ -191,12 +191,21 @@ __device__ __forceinline__ void xcorr_row14(const XcorrArgs &a, unsigned char *s
     const float4 *__restrict__ refspec4 = reinterpret_cast<const float4 *>(a.refspec) + (size_t)t * (N / 2);
 
     CRSDR_STAMP(0);
+    // folded launches: is the block's reference spectrum there yet?  ONE wave asks (r03, every wave polling: 1900 waves on one L2
+    // channel at launch start, K1 + 0.13 ms per launch whatever its size); its verdict travels through LDS at the row's first barrier
+    const unsigned int ref_early = (a.fold && tid < 64) ? word_peek(a.refflag + t) : 0u;
     c2 wA[32];                                   // column twiddles: P0 applies them, P0' their conjugates -- one chain, 62 registers
     pass0_forward<false>(A, src, twA, a.xor80, tid, wA);
     CRSDR_STAMP(1);
     // P1 / P1' twiddles: one chain per row, computed while the P0 stores drain, alive across J
     c2 wB[32];
     tw_load(wB, twB, TWB_STRIDE, tid & 15);
+    int *refok = reinterpret_cast<int *>(red) + 48;
+    if (a.fold && tid < 64) {
+        const bool ok = (unsigned int)__builtin_amdgcn_readfirstlane((int)ref_early) == a.refgen;
+        if (ok) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");      // this CU's L1 holds nothing older than the published spectrum
+        if (tid == 0) *refok = ok ? 1 : 0;
+    }
     __syncthreads();
     CRSDR_STAMP(2);
     // stagger: the two waves of a SIMD run the same program and would hit their LDS bursts and VALU
@@ -208,6 +217,12 @@ __device__ __forceinline__ void xcorr_row14(const XcorrArgs &a, unsigned char *s
     pass1_forward(A, wB, tid);
     wave_lds_sync();
     CRSDR_STAMP(3);
+    // folded launches: the block's reference spectrum comes from a workgroup of this same launch with a LOWER index (dispatched
+    // before this one: it is resident or done), published behind refflag[t]
+    if (a.fold && !*refok) {                     // workgroup-uniform; only the first rows of a launch ever come here
+        if (tid < 64 && !wait_word(a.refflag + t, a.refgen, ref_early, kRefWaitBudget) && tid == 0 && a.errflag) atomicAdd(a.errflag, 1);
+        __syncthreads();
+    }
     // junction: DFT16 . conj(ref spectrum) . IDFT16 on the same 16 contiguous points
 #pragma unroll 1     // not unrolled: both halves in flight need 238 VGPRs, one at a time 193 (room for a phase-kernel wave per SIMD)
     for (int h = 0; h < 2; ++h) {
@@ -344,17 +359,13 @@ __device__ __forceinline__ void xcorr_row14(const XcorrArgs &a, unsigned char *s
 
 
 // ---- K0: reference spectrum, conj, [slot][group] layout ------------------------------------------
-__global__ __launch_bounds__(THREADS, 2) void k_ref_spectrum14p(const int8_t *__restrict__ rows, size_t block_stride,
-                                                               const c2 *__restrict__ twA,
-                                                               const c2 *__restrict__ twB,
-                                                               float4 *__restrict__ refspec_base, uint32_t xor80)
+// one block's reference row -> conj(spectrum) in the junction's register order; whole 512-thread workgroup
+__device__ __forceinline__ void ref_spectrum_row14(unsigned char *smem, const int8_t *__restrict__ ref_row, const c2 *__restrict__ twA, const c2 *__restrict__ twB,
+                                                   float4 *__restrict__ refspec4, uint32_t xor80)
 {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     c2 *A = reinterpret_cast<c2 *>(smem);
     const float4 *A4 = reinterpret_cast<const float4 *>(smem);
     const int tid = threadIdx.x;
-    const int8_t *ref_row = rows + (size_t)blockIdx.x * block_stride; // row 0 of batch block blockIdx.x
-    float4 *refspec4 = refspec_base + (size_t)blockIdx.x * (N / 2);
     c2 wA0[32];
     pass0_forward<true>(A, ref_row, twA, xor80, tid, wA0);
     c2 wB[32];
@@ -378,6 +389,15 @@ __global__ __launch_bounds__(THREADS, 2) void k_ref_spectrum14p(const int8_t *__
         for (int j = 0; j < 8; ++j) // conj(sfft[0]) for the conjugate multiply of src/ccoherent.cc:177-179
             refspec4[j * 1024 + g] = make_float4(u[2 * j].x, -u[2 * j].y, u[2 * j + 1].x, -u[2 * j + 1].y);
     }
+}
+__global__ __launch_bounds__(THREADS, 2) void k_ref_spectrum14p(const int8_t *__restrict__ rows, size_t block_stride,
+                                                               const c2 *__restrict__ twA,
+                                                               const c2 *__restrict__ twB,
+                                                               float4 *__restrict__ refspec_base, uint32_t xor80)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    ref_spectrum_row14(smem, rows + (size_t)blockIdx.x * block_stride /* row 0 of batch block blockIdx.x */, twA, twB,
+                       refspec_base + (size_t)blockIdx.x * (N / 2), xor80);
 }
 
 // ---- 16384-point row transforms on cf32 lines (stage B of the long-block path, longblock.hpp) ---------
@@ -575,11 +595,27 @@ __global__ __launch_bounds__(THREADS, 2) void k_rows14_cf32p(c2 *__restrict__ Y,
 }
 
 
+// grid: fold * blocks + owned rows * blocks workgroups, one-dimensional.  fold = 1: the first `blocks` workgroups are the blocks'
+// reference items -- every one of them has a lower index than any row workgroup, so in-order dispatch has them all resident (or done)
+// before a row can wait for one, and only the first rows of a launch ever do (with the reference item NEXT to its block's rows,
+// index t * (rows + 1), every block's rows were dispatched beside their own reference item and stood still for its ~9 us: measured
+// r03, K1 0.117 -> 0.274 ms per 2560-row launch).
 __global__ __launch_bounds__(THREADS, 2) void k_xcorr_lag14p(XcorrArgs a, const float2 *__restrict__ twA,
-                                                             const float2 *__restrict__ twB)
+                                                             const float2 *__restrict__ twB, int row_count)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int row = a.row_begin + blockIdx.x, t = blockIdx.y;
+    const int nref = a.fold ? a.nblocks : 0;
+    const int id = (int)blockIdx.x - nref;
+    const int t = id < 0 ? (int)blockIdx.x : id / row_count, x = id < 0 ? -1 : id % row_count;
+    if (x < 0) {
+        ref_spectrum_row14(smem, a.rows + (size_t)t * a.block_stride, reinterpret_cast<const c2 *>(twA), reinterpret_cast<const c2 *>(twB),
+                           reinterpret_cast<float4 *>(a.refspec_w) + (size_t)t * (N / 2), a.xor80);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");       // this wave's spectrum stores are visible device-wide ...
+        __syncthreads();                                          // ... and so are every wave's, before the word says so
+        if (threadIdx.x == 0) __hip_atomic_store(a.refflag + t, a.refgen, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        return;
+    }
+    const int row = a.row_begin + x;
     if (xcorr_skip(a, row, t, threadIdx.x)) return;
     xcorr_row14(a, smem, a.rows + (size_t)t * a.block_stride + (size_t)row * N, row, t,
                 reinterpret_cast<const c2 *>(twA), reinterpret_cast<const c2 *>(twB));
