@@ -269,7 +269,7 @@ static hipError_t launch_xcorr_lag14(hipStream_t s, const XcorrArgs &a, int row_
 {
     const int cus = device_cus();
     const int rows_all = row_count * a.nblocks, items = rows_all + (a.fold ? a.nblocks : 0);
-    const char variant = k1_pick(rows_all, allow_q);
+    const char variant = a.fold ? 'p' : k1_pick(rows_all, allow_q);      // (the caller folds the reference spectra in only where the packed kernel runs)
     if (used_q) *used_q = variant == 'q';
     // a launch with bounded waits (the two-row kernel's, a folded launch's wait for its reference spectra) snapshots the carried state first
     if ((variant == 'q' || a.fold) && before_bounded) { hipError_t eb = before_bounded(); if (eb != hipSuccess) return eb; }

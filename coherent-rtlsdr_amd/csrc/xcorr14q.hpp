@@ -39,7 +39,6 @@ struct QSync {
     int next[2];    // the item each group takes after its current one (drawn one row ahead by the group's first lane)
     int spin_limit; // polls a wait may take (kQSpinLimit; a test forces 0 to see the error path)
     int arrive[2];  // waves of each group that have published their argmax candidate (monotonic: the fourth of a row finishes it)
-    int refok[2];   // folded launches: item + 1 of the row whose block's reference spectrum the group's first wave has seen published
 };
 static_assert(sizeof(QSync) <= 64, "QSync must fit the 64 bytes reserved behind the scratch");
 
@@ -104,8 +103,7 @@ __device__ __forceinline__ void q_release(QSync *s)
     }
 }
 
-// P0 of one virtual thread without the stores (pass0_forward<IS_REF> of xcorr14p.hpp)
-template <bool IS_REF = false>
+// P0 of one virtual thread without the stores (pass0_forward<false> of xcorr14p.hpp)
 __device__ __forceinline__ void q_p0_compute(c2 *v, const int8_t *__restrict__ row, const c2 *__restrict__ twA, uint32_t xor80, int vt)
 {
     const uint16_t *src = reinterpret_cast<const uint16_t *>(row);
@@ -115,7 +113,7 @@ __device__ __forceinline__ void q_p0_compute(c2 *v, const int8_t *__restrict__ r
         const uint32_t u = (uint32_t)src[i * 512 + vt] ^ x16;
         v[i] = mk((float)sext8(u, 0), (float)sext8(u, 1));
     }
-    dft32_stage1_pruned<0, IS_REF>(v);
+    dft32_stage1_pruned<0, false>(v);
     dft16p<-1>(v);
     dft16p<-1>(v + 16);
     c2 w[32];
@@ -186,24 +184,6 @@ __device__ __forceinline__ void q_junction_half(float4 *A4, const float4 *r, int
 #pragma unroll
     for (int j = 0; j < 8; ++j)
         A4[base + (j ^ key)] = make_float4(u[2 * j].x, u[2 * j].y, u[2 * j + 1].x, u[2 * j + 1].y);
-}
-
-// junction of a REFERENCE item, one half: forward DFT16, conjugate, out to the spectrum (what k_ref_spectrum14p stores)
-__device__ __forceinline__ void q_ref_junction_half(const float4 *A4, float4 *__restrict__ refspec4, int vt, int h)
-{
-    const int g = ((vt >> 6) << 7) + 64 * h + (vt & 63), key = g & 7;
-    int base = j_base(g);
-    asm volatile("" : "+v"(base));
-    c2 u[16];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const float4 q = A4[base + (j ^ key)];
-        u[2 * j] = mk(q.x, q.y);
-        u[2 * j + 1] = mk(q.z, q.w);
-    }
-    dft16p<-1>(u);
-#pragma unroll
-    for (int j = 0; j < 8; ++j) refspec4[j * 1024 + g] = make_float4(u[2 * j].x, -u[2 * j].y, u[2 * j + 1].x, -u[2 * j + 1].y);
 }
 
 __device__ __forceinline__ float q_wave_max63(float wm)
@@ -318,18 +298,13 @@ __global__ __launch_bounds__(2 * QG, 1) void k_xcorr_lag14q(XcorrArgs a, const f
     int *redi = reinterpret_cast<int *>(red);
     float *edge = red + 16;                                                                      // [wave][first lane, last lane][half * 32 + i]
     QSync *sy = reinterpret_cast<QSync *>(smem + (size_t)LDS_ELEMS * 8 + 2 * QSCR_BYTES);
-    if (threadIdx.x == 0) { sy->owner = 0; sy->relcnt = 0; sy->bar[0] = 0; sy->bar[1] = 0; sy->err = 0; sy->next[0] = 0; sy->next[1] = 0; sy->spin_limit = spin_limit; sy->arrive[0] = 0; sy->arrive[1] = 0; sy->refok[0] = 0; sy->refok[1] = 0; }
+    if (threadIdx.x == 0) { sy->owner = 0; sy->relcnt = 0; sy->bar[0] = 0; sy->bar[1] = 0; sy->err = 0; sy->next[0] = 0; sy->next[1] = 0; sy->spin_limit = spin_limit; sy->arrive[0] = 0; sy->arrive[1] = 0; }
     __syncthreads();
     int gen = 0;
 #ifdef CRSDR_QDEBUG
     const unsigned long long tk0__ = __builtin_readcyclecounter();
 #endif
-    // fold = 1: items [0, nblocks) are the blocks' REFERENCE rows (forward transform, conj, out to the spectrum, refflag[t] published),
-    // the signal rows follow; a row waits for its block's word BEFORE it asks for the image (holding the image while the other
-    // group of this very workgroup needs it for that reference item would never end).  Items are handed out in increasing order,
-    // so a reference item is always in the hands of a resident group (or done) by the time a row of its block is drawn.
-    const int nref = a.fold ? a.nblocks : 0;
-    const int nitems = nref + row_count * a.nblocks;
+    const int nitems = row_count * a.nblocks;
     // Work order: each group starts on item g * gridDim.x + blockIdx.x and draws every further one from a global counter
     // (*work counts on from work_base; it advances by exactly nitems per launch -- every item after the first 2 * grid
     // is one draw, and every group that had an item makes one draw that comes back empty -- so the host never resets it).
@@ -343,47 +318,7 @@ __global__ __launch_bounds__(2 * QG, 1) void k_xcorr_lag14q(XcorrArgs a, const f
         asm volatile("" : "+v"(vt0), "+v"(vt1));
         if ((unsigned)item >= (unsigned)nitems) break;     // also ends on a negative item (host / device counters out of step)
         const int item_u = __builtin_amdgcn_readfirstlane(item);           // one item per group: scalar row / block addresses
-        if (item_u < nref) {
-            const int8_t *rsrc = a.rows + (size_t)item_u * a.block_stride;
-            float4 *__restrict__ rs4 = reinterpret_cast<float4 *>(a.refspec_w) + (size_t)item_u * (N / 2);
-            c2 wBr[32];
-            {
-                c2 v[32], v2[32];
-                q_p0_compute<true>(v, rsrc, twA, a.xor80, vt0);
-                q_p0_compute<true>(v2, rsrc, twA, a.xor80, vt1);
-                tw_load(wBr, twB, TWB_STRIDE, tid & 15);
-                q_acquire(sy, 2 * k + g + 1);
-                __builtin_amdgcn_s_setprio(Q_PRIO);
-                q_p0_store(A, v, vt0);
-                q_p0_store(A, v2, vt1);
-            }
-            q_barrier(sy, g, gen, 0);
-            int drawn_r = 0;
-            if (tid == 0) drawn_r = 2 * (int)gridDim.x + (int)(atomicAdd(work, 1u) - work_base);
-            pass1_forward(A, wBr, vt0);
-            pass1_forward(A, wBr, vt1);
-            wave_lds_sync();
-            q_ref_junction_half(A4, rs4, vt0, 0);
-            q_ref_junction_half(A4, rs4, vt0, 1);
-            q_ref_junction_half(A4, rs4, vt1, 0);
-            q_ref_junction_half(A4, rs4, vt1, 1);
-            if (tid == 0) sy->next[g] = drawn_r;
-            q_barrier(sy, g, gen, 1);
-            q_release(sy);                               // every wave has read its junction groups: the image goes to the other group
-            __builtin_amdgcn_s_setprio(0);
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");      // this wave's spectrum stores are visible device-wide before it says "arrived"
-            int arr = 0;
-            if ((tid & 63) == 0) arr = __hip_atomic_fetch_add(&sy->arrive[g], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            arr = __builtin_amdgcn_readfirstlane(arr);
-            if ((arr & 3) == 3 && (tid & 63) == 0) {     // the last of the four waves publishes
-                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "agent");
-                __hip_atomic_store(a.refflag + item_u, a.refgen, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-            }
-            item = sy->next[g];
-            continue;
-        }
-        const int ritem = item_u - nref;
-        const int t = ritem / row_count, row = a.row_begin + ritem % row_count;
+        const int t = item_u / row_count, row = a.row_begin + item_u % row_count;
         if (xcorr_skip(a, row, t, tid)) {
             q_barrier(sy, g, gen, 5);           // every wave of the group has read this item from next[g] before it is overwritten
             if (tid == 0) sy->next[g] = 2 * (int)gridDim.x + (int)(atomicAdd(work, 1u) - work_base);
@@ -393,32 +328,12 @@ __global__ __launch_bounds__(2 * QG, 1) void k_xcorr_lag14q(XcorrArgs a, const f
         }
         const int8_t *src = a.rows + (size_t)t * a.block_stride + (size_t)row * N;
         const float4 *__restrict__ refspec4 = reinterpret_cast<const float4 *>(a.refspec) + (size_t)t * (N / 2);
-        const unsigned int ref_early = (a.fold && tid < 64) ? word_peek(a.refflag + t) : 0u;      // the group's first wave asks now; needed after the first pass's arithmetic
         c2 wB[32];
         {
             c2 v[32], v2[32];
             q_p0_compute(v, src, twA, a.xor80, vt0);      // no LDS yet: both halves run beside the other group's middle section
             q_p0_compute(v2, src, twA, a.xor80, vt1);
             tw_load(wB, twB, TWB_STRIDE, tid & 15);       // P1 / P1' twiddles: table loads and product chain outside the ownership window
-            if (a.fold) {
-                // the block's reference spectrum comes from a lower item of this launch.  The group's first wave watches the device word
-                // (one poller per group: hundreds of waves polling one L2 channel crowd the publisher's own traffic out) and hands its
-                // verdict to the other three through LDS, tagged with the item
-                if (tid < 64) {
-                    if (!wait_word(a.refflag + t, a.refgen, ref_early, sy->spin_limit)) __hip_atomic_store(&sy->err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    if (tid == 0) __hip_atomic_store(&sy->refok[g], item_u + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-                } else {
-                    int spins = 0;
-                    while (__hip_atomic_load(&sy->refok[g], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != item_u + 1) {
-                        if (++spins > sy->spin_limit || __hip_atomic_load(&sy->err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) {
-                            __hip_atomic_store(&sy->err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                            break;
-                        }
-                        __builtin_amdgcn_s_sleep(1);
-                    }
-                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-                }
-            }
             q_acquire(sy, 2 * k + g + 1);
             __builtin_amdgcn_s_setprio(Q_PRIO);                // the owner's window is what the pair's period is made of
             q_p0_store(A, v, vt0);
@@ -613,7 +528,7 @@ __global__ __launch_bounds__(2 * QG, 1) void k_rows14_cf32q(c2 *__restrict__ Y, 
     float4 *A4 = reinterpret_cast<float4 *>(smem);
     const int g = threadIdx.x >> 8, tid = threadIdx.x & (QG - 1);
     QSync *sy = reinterpret_cast<QSync *>(smem + (size_t)LDS_ELEMS * 8 + 2 * QSCR_BYTES);
-    if (threadIdx.x == 0) { sy->owner = 0; sy->relcnt = 0; sy->bar[0] = 0; sy->bar[1] = 0; sy->err = 0; sy->next[0] = 0; sy->next[1] = 0; sy->spin_limit = spin_limit; sy->arrive[0] = 0; sy->arrive[1] = 0; sy->refok[0] = 0; sy->refok[1] = 0; }
+    if (threadIdx.x == 0) { sy->owner = 0; sy->relcnt = 0; sy->bar[0] = 0; sy->bar[1] = 0; sy->err = 0; sy->next[0] = 0; sy->next[1] = 0; sy->spin_limit = spin_limit; sy->arrive[0] = 0; sy->arrive[1] = 0; }
     __syncthreads();
     int gen = 0;
     const int q = (int)blockIdx.x % nq, nlocal = 2 * ((int)gridDim.x / nq);           // this workgroup's queue; groups working on it
