@@ -368,17 +368,9 @@ static hipError_t launch_long_rows_q(hipStream_t s, int n1, int nrows_launch, fl
     if (e != hipSuccess) return e;
     const int items = n1 * nrows_launch;
     static const int qspin = [] { const char *ev = getenv("CRSDR_K1_QSPIN"); return ev ? atoi(ev) : x14p::kQSpinLimit; }();
-    // Whole rounds: a launch of `items` lines takes ceil(items / (2 cus)) rounds of two lines per CU, and the stage is bound by the bytes
-    // it moves, not by CUs -- so the lines are dealt to just as many workgroups as make every round full (cfg5: 2688 lines = 6 rounds
-    // x 448 groups on 224 CUs, instead of 5 full rounds on 256 CUs and a sixth with 128 lines on 128 CUs at a quarter of the bandwidth)
-    static const int balance = [] { const char *ev = getenv("CRSDR_LONG_BALANCE"); return ev ? atoi(ev) : 1; }();
-    const int rounds = std::max(1, (items + 2 * cus - 1) / (2 * cus));
-    int grid = std::max(1, std::min(cus, (items + 1) / 2));
-    if (balance && items > 2 * cus) {
-        int gbal = (items + 2 * rounds - 1) / (2 * rounds);
-        gbal = (gbal + 7) / 8 * 8;                               // whole XCD octets (the per-XCD queues below)
-        if (gbal <= cus) grid = gbal;
-    }
+    // (r03: dealing the lines to just as many workgroups as make every round full -- cfg5: 2688 lines = 6 rounds x 448 groups on 224
+    // CUs instead of 5 full rounds and a sixth with 128 lines -- measured level: 2 473 / 2 544 against 2 500 / 2 549 blocks/s)
+    const int grid = std::max(1, std::min(cus, (items + 1) / 2));
     // one queue per XCD (k_rows14_cf32q); static order: the work counter is not used.  (The apply pass's per-row spectra are
     // 2.7 MB for cfg5 and stay in every L2: lines in memory order there.)
     const int nq = (!ramp && n1 % 8 == 0 && grid % 8 == 0) ? 8 : 1;
