@@ -426,6 +426,17 @@ static hipError_t launch_long_inv_cols(hipStream_t s, int nrows_launch, const fl
     return hipGetLastError();
 }
 
+template <int LOG2N>
+static hipError_t launch_frac_apply(hipStream_t s, int row_count, int nblocks, const FracArgs &fa, const float2 *tw)
+{
+    auto kern = k_frac_apply<LOG2N>;
+    constexpr size_t lds = sizeof(float2) * ((size_t)1 << LOG2N) + 256;
+    hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(kern, dim3(row_count, nblocks), dim3(FftGeom<LOG2N>::THREADS), lds, s, fa, tw);
+    return hipGetLastError();
+}
+
 #define CRSDR_DISPATCH_LOG2(l2, CALL)                                                   \
     [&]() -> hipError_t {                                                               \
         switch (l2) {                                                                   \
@@ -839,8 +850,6 @@ static int make_k2tab(crsdr_plan *p)
     }
     HIP_TRY(hipMalloc((void **)&p->d_k2tab, sizeof(uint32_t) * tab.size()));
     HIP_TRY(hipMemcpy(p->d_k2tab, tab.data(), sizeof(uint32_t) * tab.size(), hipMemcpyHostToDevice));
-    HIP_TRY(hipMalloc((void **)&p->d_frac_override, sizeof(float) * (size_t)p->nrows));
-    HIP_TRY(hipMemset(p->d_frac_override, 0, sizeof(float) * (size_t)p->nrows));
     return CRSDR_OK;
 }
 
@@ -919,6 +928,8 @@ static int plan_alloc(crsdr_plan *p)
     HIP_TRY(hipHostMalloc((void **)&p->h_readcnt, sizeof(uint32_t) * n * T * kStageSlots, hipHostMallocDefault));
     HIP_TRY(hipHostMalloc((void **)&p->h_mask, n * kStageSlots, hipHostMallocDefault));
     if (p->longblock) { int rc = make_k2tab(p); if (rc) return rc; }
+    HIP_TRY(hipMalloc((void **)&p->d_frac_override, sizeof(float) * (size_t)p->nrows));
+    HIP_TRY(hipMemset(p->d_frac_override, 0, sizeof(float) * (size_t)p->nrows));
     return plan_init_state(p);
 }
 
@@ -1094,8 +1105,8 @@ extern "C" int crsdr_plan_set_frac_apply(crsdr_plan *p, int enable, float gain, 
         p->frac_apply = false;
         return CRSDR_OK;
     }
-    if (!p->longblock || p->mode != CRSDR_MODE_DIGITAL)
-        return fail(CRSDR_EINVAL, "plan_set_frac_apply: needs a long-block plan (blocksize > 16384) in CRSDR_MODE_DIGITAL");
+    if (p->mode != CRSDR_MODE_DIGITAL)
+        return fail(CRSDR_EINVAL, "plan_set_frac_apply: needs a plan in CRSDR_MODE_DIGITAL (the faithful mode never shifts samples)");
     // |D| is bounded: the response's phase k_s D / B is formed in fp32 (cis2pi), whose argument loses 6e-8 of its size per ulp --
     // at |D| <= 64 samples the phase stays within 1e-5 rad.  A proper peak's parabolic estimate is |frac| <= 1/2, so D = gain * frac
     // needs |gain| <= 128; caller-supplied delays beyond the bound belong in the integer lag (the resampler servo's business).
@@ -1109,6 +1120,10 @@ extern "C" int crsdr_plan_set_frac_apply(crsdr_plan *p, int enable, float gain, 
         int rc = crsdr_plan_sync(p);
         if (rc) return rc;
         HIP_TRY(hipMemcpy(p->d_frac_override, frac_override, sizeof(float) * (size_t)p->nrows, hipMemcpyHostToDevice));
+    }
+    if (!p->longblock) {                   // LDS-resident blocks: one kernel behind the phase kernels, nothing to allocate
+        p->frac_apply = true; p->frac_gain = gain; p->frac_override_on = frac_override != nullptr;
+        return CRSDR_OK;
     }
     if (!p->d_rowspec) HIP_TRY(hipMalloc((void **)&p->d_rowspec, sizeof(float4) * 8192 * (size_t)p->row_count));
     if (enable == 2 && p->d_Z) {           // memory-lean form asked for: give the second work area back
@@ -1413,6 +1428,12 @@ extern "C" int crsdr_plan_submit_batch(crsdr_plan *p, const void *rows, int mem_
             else hipLaunchKernelGGL((k_align_fused<false, true>), grid, dim3(kAlignThreads), 0, S, aa, fs);
         }
         HIP_TRY(hipGetLastError());
+        if (p->frac_apply && !p->longblock && aa.digital) {
+            // fractional-delay correction of LDS-resident blocks: the owned rows once more, through the frequency domain
+            FracArgs fa{d_in, d_stride, p->d_packet, p->packet_stride, p->d_slab, p->slab_stride, p->nrows, p->row_begin, xor80, o_lag, o_frac,
+                        p->frac_override_on ? p->d_frac_override : nullptr, p->frac_gain, p->d_phasor};
+            HIP_TRY(CRSDR_DISPATCH_LOG2(p->log2n, (launch_frac_apply<LG>(S, p->row_count, nblocks, fa, p->d_tw))));
+        }
         if (pe) HIP_TRY(hipEventRecord(pe[1], S));
         { int rc_ = pack_tails(p, S, nblocks, o_lag, o_mag, o_frac); if (rc_) return rc_; }
         HIP_TRY(hipEventRecord(p->ev_k2done[obuf], S));
@@ -1477,6 +1498,10 @@ extern "C" int crsdr_plan_submit_batch(crsdr_plan *p, const void *rows, int mem_
                     HIP_TRY(launch_long_rows_ramp(S, n1, cnt, Yc, p->d_twA, p->d_twB, ra));
                 HIP_TRY(CRSDR_DISPATCH_N1(l1, (launch_long_out_cols<LG>(S, cnt, Yc, tw, obase + (size_t)r0 * (size_t)p->B))));
             }
+        } else if (p->frac_apply && !p->longblock && aa.digital) {       // LDS-resident blocks on the three-kernel path: as behind the fused kernel
+            FracArgs fa{d_in, d_stride, p->d_packet, p->packet_stride, p->d_slab, p->slab_stride, p->nrows, p->row_begin, xor80, o_lag, o_frac,
+                        p->frac_override_on ? p->d_frac_override : nullptr, p->frac_gain, p->d_phasor};
+            HIP_TRY(CRSDR_DISPATCH_LOG2(p->log2n, (launch_frac_apply<LG>(S, p->row_count, nblocks, fa, p->d_tw))));
         }
         if (pe) HIP_TRY(hipEventRecord(pe[1], S));
     }

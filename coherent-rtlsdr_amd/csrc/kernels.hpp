@@ -820,6 +820,74 @@ __global__ __launch_bounds__(kAlignThreads, 8) void k_align_fused(AlignArgs a_, 
     }
 }
 
+// ---- fractional-delay correction for LDS-resident blocks (B <= 16384; crsdr_plan_set_frac_apply) ---------------------------
+// The long-block form (longblock.hpp stages A, B'', C'') for a row that fits one workgroup's LDS: int8 row -> zero-padded forward
+// transform -> every bin times H[f] = p / B . exp(+2 pi i f_s (lag + D) / B) (f_s the signed bin index) -> inverse transform -> the
+// first L samples quantised like cdsp::convto8bit, over the row the phase kernel has just written (shifted by the integer lag
+// only).  One workgroup per (owned row, block), the generic in-LDS network of fft_lds.hpp (DIF forward leaves digit-reversed
+// order, the DIT inverse takes it back: the response is looked up at the bin a position holds).  The integer part of the
+// exponent is reduced mod B in integers and read from the plan's forward table, the fractional part |f_s D / B| <= 1/2 . |D| by
+// polynomial (x14p::cis2pi) -- as in the long-block pass; the oracle (oracle/coherent_oracle.c: frac_apply_row) forms the ramp in
+// double and rounds once: equal except +-1 LSB on a few entries per thousand (tests/test_gpu_fracdelay.py).
+struct FracArgs {
+    const int8_t *rows;
+    size_t block_stride;
+    int8_t *packet;
+    size_t packet_stride;
+    int8_t *slab;              // slab output (sharded plans) or nullptr
+    size_t slab_stride;
+    int nrows, row_begin;
+    uint32_t xor80;
+    const int32_t *lag;        // [T][nrows] this batch's lags
+    const float *frac;         // [T][nrows] this batch's parabolic estimates
+    const float *frac_override; // [nrows] or nullptr: D = gain * frac
+    float gain;
+    const float2 *phasor;      // [T][nrows] get_phasecorrect() after each block
+};
+
+template <int LOG2N>
+__global__ __launch_bounds__(FftGeom<LOG2N>::THREADS) void k_frac_apply(FracArgs a, const float2 *__restrict__ tw)
+{
+    using G = FftGeom<LOG2N>;
+    constexpr int N = G::N, L = N / 2;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float2 *A = reinterpret_cast<float2 *>(smem);
+    const int tid = threadIdx.x, t = blockIdx.y;
+    const int row = a.row_begin + (int)blockIdx.x;
+    const size_t o = (size_t)t * a.nrows + row;
+    load_row_to_lds<LOG2N>(A, a.rows + (size_t)t * a.block_stride + (size_t)row * N, false, a.xor80, tid);
+    __syncthreads();
+    fft_dif_range<LOG2N, -1, 0, G::NPASS>(A, tw, tid);
+    {
+        const uint32_t lagu = (uint32_t)a.lag[o];
+        const float D = a.frac_override ? a.frac_override[row] : a.gain * a.frac[o];
+        const float2 pr = a.phasor[o];
+        const float invN = 1.0f / (float)N;
+        const float2 pb = make_float2(pr.x * invN, pr.y * invN);
+        const float dstep = D * invN;
+        for (int j = tid; j < N; j += G::THREADS) {
+            const int f = digit_reverse<LOG2N>(j);                      // A[j] holds bin f
+            const int fs = f < L ? f : f - N;
+            const float2 w = tw[((uint32_t)f * lagu) & (uint32_t)(N - 1)];      // W_N^m = exp(-2 pi i m / N): its conjugate is the integer part
+            const c2 cf = x14p::cis2pi((float)fs * dstep);
+            const float2 h = cmul(cmulc(pb, w), make_float2(cf.x, cf.y));
+            A[j] = cmul(A[j], h);
+        }
+    }
+    __syncthreads();
+    fft_dit_range<LOG2N, +1, 0, G::NPASS>(A, tw, tid);
+    // cpacketize::write(complex<float>*) -> cdsp::convto8bit (src/cpacketizer.cc:158-172, src/cdsp.cc:51-54) on the first L samples
+    int8_t *orow = a.slab ? a.slab + (size_t)t * a.slab_stride + (size_t)(row - a.row_begin) * N
+                          : a.packet + (size_t)t * a.packet_stride + 16 + 4 * (size_t)a.nrows + (size_t)row * N;
+    uint32_t *o32 = reinterpret_cast<uint32_t *>(orow);
+    for (int i = tid; i < L / 2; i += G::THREADS) {
+        const float2 x = A[2 * i], y = A[2 * i + 1];
+        const uint32_t b0 = (uint32_t)(uint8_t)f32_to_i8(x.x), b1 = (uint32_t)(uint8_t)f32_to_i8(x.y), b2 = (uint32_t)(uint8_t)f32_to_i8(y.x),
+                       b3 = (uint32_t)(uint8_t)f32_to_i8(y.y);
+        o32[i] = b0 | (b1 << 8) | (b2 << 16) | (b3 << 24);
+    }
+}
+
 // ---- slab assembly on a gather root ---------------------------------------------------
 // recv [nsrc][nblocks][slab_words] (what an all-to-all of the ranks' slab buffers delivers) -> the matrix rows
 // 1 + src*per .. of packet j.  Pure copy, grid (chunks, nblocks, nsrc).

@@ -204,7 +204,9 @@ int crsdr_plan_fetch_block(crsdr_plan *plan, int block, int32_t *lag, float *mag
  * "Fractional delay": report D and, if applied, apply it as a linear phase ramp in the frequency domain).  The reference
  * computes a 3-point estimate and discards it (src/ccoherent.cc:206-219); its authors' study of applying one
  * (matlabclient/notes.m:9-40) finds a signal-dependent gain between estimate and true delay, hence `gain` / the override.
- * Long-block plans (blocksize > 16384) in CRSDR_MODE_DIGITAL only; off by default (the reference-faithful behaviour).
+ * CRSDR_MODE_DIGITAL only; off by default (the reference-faithful behaviour).  Every block size: long blocks (blocksize > 16384) run a
+ * second four-step pass (below), LDS-resident blocks one extra kernel per batch behind the phase kernels (row -> forward transform ->
+ * x the response -> inverse -> int8 over the row the phase kernel wrote), for which enable = 1 and 2 are the same and nothing is allocated.
  * With it on, row k of the matrix is the row advanced by lag_k + D_k samples -- a circular advance of the zero-padded row in
  * the frequency domain: X[f] * exp(+2 pi i f_s (lag_k + D_k) / B), f_s the signed bin index -- then rotated by the phasor
  * and quantised like cdsp::convto8bit; for D = 0 that is the digital mode's zero-filled integer shift.

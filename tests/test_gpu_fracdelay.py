@@ -159,10 +159,65 @@ def test_cfg5_full_size_with_fractional_delays(b, oracle, synth):
     plan.close()
 
 
+@pytest.mark.parametrize("log2B", [6, 10, 13, 14])
+def test_frac_apply_on_lds_resident_blocks(b, oracle, model, synth, log2B):
+    # The correction at the reference's own block size (B = 16384) and below: one kernel behind the phase kernels (int8 row ->
+    # forward transform -> x exp(2 pi i f_s (lag + D) / B) . p / B -> inverse -> int8) instead of the long blocks' second four-step
+    # pass.  Same definition, so the same checks as test_frac_apply_matches_oracle_and_fp64_model: matrix equal to the oracle and
+    # to the fp64 model except +-1 LSB on a few entries per thousand, the raw reference row and the header untouched, batched
+    # submits equal to block-by-block submits bit for bit, a row with D = 0 equal to the plain digital mode to rounding.
+    nsig, B = 5, 1 << log2B
+    L = B // 2
+    seed = 700 + log2B
+    params = synth.RowParams(nsig, L, seed, dmax=max(1, L // 8))
+    D = np.array([0.0, 0.5, -0.25, 0.3, 0.0, -0.45], dtype=np.float32)
+    T = 3
+    plan, orc, mod = b.Plan(nsig + 1, B, b.MODE_DIGITAL, max_batch=T), oracle.Engine(nsig + 1, B, oracle.DIGITAL), model.Model(nsig + 1, B, model.DIGITAL)
+    for x in (plan, orc, mod):
+        x.set_frac_apply(True, 1.0, D)
+    blocks = [synth.make_block(nsig, L, seed, t, params=params)[0] for t in range(2 * T)]
+    single = []
+    for t in range(T):
+        got, exp = plan.block(blocks[t], seq=t), orc.block(blocks[t], seq=t)
+        single.append(got)
+        assert np.array_equal(got["lag"], exp["lag"])
+        assert np.abs(np.angle(got["phasor"][1:] * np.conj(exp["phasor"][1:]))).max() <= 1e-5
+        # short rows have few samples per quantisation boundary: allow the same fraction, at least a handful of entries
+        frac_allowed = max(2e-3, 4.0 / got["matrix"].size)
+        _matrix_close(got["matrix"], exp["matrix"], frac_allowed)
+        _matrix_close(got["matrix"], mod.block(blocks[t])[4], frac_allowed)
+        assert np.array_equal(got["matrix"][0], blocks[t][0])
+        assert np.array_equal(got["packet"][:plan.matrix_offset], exp["packet"][:orc.matrix_offset])
+    # one batched submit of the same three blocks on a fresh plan: bit for bit what the three single submits gave
+    plan2 = b.Plan(nsig + 1, B, b.MODE_DIGITAL, max_batch=T)
+    plan2.set_frac_apply(True, 1.0, D)
+    plan2.submit(np.stack(blocks[:T]), seq=0)
+    for t in range(T):
+        out = plan2.fetch(block=t)
+        for key in ("lag", "mag", "frac", "phasor", "packet"):
+            assert np.array_equal(out[key].view(np.uint8), single[t][key].view(np.uint8)), (t, key)
+    # rows 4 has D = 0: the frequency-domain path reproduces the zero-filled integer shift of the plain digital mode to rounding
+    plain = b.Plan(nsig + 1, B, b.MODE_DIGITAL, max_batch=T)
+    for t in range(T):
+        ref_out = plain.block(blocks[t], seq=t)
+    _matrix_close(single[T - 1]["matrix"][4:5], ref_out["matrix"][4:5], max(2e-3, 4.0 / B))
+    # estimate-driven, then off again
+    plan.set_frac_apply(True, 1.0, None)
+    orc.set_frac_apply(True, 1.0, None)
+    got, exp = plan.block(blocks[T], seq=T), orc.block(blocks[T], seq=T)
+    assert np.allclose(got["frac"], exp["frac"], atol=5e-3)
+    _matrix_close(got["matrix"], exp["matrix"], 3e-2)
+    plan.set_frac_apply(False)
+    plain.block(blocks[T], seq=T)
+    got, exp = plan.block(blocks[T + 1], seq=T + 1), plain.block(blocks[T + 1], seq=T + 1)
+    assert np.array_equal(got["lag"], exp["lag"])
+    for p_ in (plan, plan2, plain):
+        p_.close()
+
+
 def test_frac_apply_argument_checks(b):
     short = b.Plan(3, 16384, b.MODE_DIGITAL)
-    with pytest.raises(b.CrsdrError):
-        short.set_frac_apply(True)                    # LDS-resident blocks: not offered (config 5 is the long-block regime)
+    short.set_frac_apply(True)                        # LDS-resident blocks: offered since r03 (one kernel behind the phase kernels)
     short.set_frac_apply(False)                       # switching it off is always fine
     faithful = b.Plan(3, 1 << 15, b.MODE_FAITHFUL)
     with pytest.raises(b.CrsdrError):
