@@ -827,8 +827,7 @@ __global__ __launch_bounds__(kAlignThreads, 8) void k_align_fused(AlignArgs a_, 
 // only).  One workgroup per (owned row, block), the generic in-LDS network of fft_lds.hpp (DIF forward leaves digit-reversed
 // order, the DIT inverse takes it back: the response is looked up at the bin a position holds).  The integer part of the
 // exponent is reduced mod B in integers and read from the plan's forward table, the fractional part |f_s D / B| <= 1/2 . |D| by
-// polynomial (x14p::cis2pi) -- as in the long-block pass; the oracle (oracle/coherent_oracle.c: frac_apply_row) forms the ramp in
-// double and rounds once: equal except +-1 LSB on a few entries per thousand (tests/test_gpu_fracdelay.py).
+// polynomial (x14p::cis2pi) -- as in the long-block pass; the CPU checker forms the ramp in double and rounds once: equal except +-1 LSB on a few entries per thousand (tests/test_gpu_fracdelay.py).
 struct FracArgs {
     const int8_t *rows;
     size_t block_stride;
