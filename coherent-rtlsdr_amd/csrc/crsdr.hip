@@ -461,8 +461,8 @@ static hipError_t launch_frac_apply(hipStream_t s, int row_count, int nblocks, c
 namespace {
 struct OpCtx {
     std::mutex mu;
-    void *buf[3] = {nullptr, nullptr, nullptr};
-    size_t cap[3] = {0, 0, 0};
+    void *buf[4] = {nullptr, nullptr, nullptr, nullptr};      // [3]: the tiled covariance's partial sums
+    size_t cap[4] = {0, 0, 0, 0};
     float2 *tw[kMaxLog2 + 1] = {};
     int tw_dev[kMaxLog2 + 1] = {};
     int dev = -1;
@@ -474,7 +474,7 @@ int op_reserve(int slot, size_t bytes)
     int dev = 0;
     HIP_TRY(hipGetDevice(&dev));
     if (g_op.dev != dev) {
-        for (int i = 0; i < 3; ++i) { if (g_op.buf[i]) (void)hipFree(g_op.buf[i]); g_op.buf[i] = nullptr; g_op.cap[i] = 0; }
+        for (int i = 0; i < 4; ++i) { if (g_op.buf[i]) (void)hipFree(g_op.buf[i]); g_op.buf[i] = nullptr; g_op.cap[i] = 0; }
         for (int i = 0; i <= kMaxLog2; ++i) { if (g_op.tw[i]) (void)hipFree(g_op.tw[i]); g_op.tw[i] = nullptr; }
         g_op.dev = dev;
     }
@@ -629,9 +629,22 @@ extern "C" int crsdr_covariance(float *rxx, const int8_t *matrix, int nrows, int
     }
     hipLaunchKernelGGL(cov::k_row_sums, dim3(nrows), dim3(256), 0, 0, d_m, blocksize, (int2 *)g_op.buf[2]);
     HIP_TRY(hipGetLastError());
-    const unsigned tiles = (unsigned)((nsig + 63) / 64);
-    hipLaunchKernelGGL(cov::k_covariance, dim3(tiles, tiles), dim3(256), 0, 0, d_m, nrows, blocksize, (const int2 *)g_op.buf[2], d_r);
-    HIP_TRY(hipGetLastError());
+    if (blocksize % cov::KC == 0 && (uintptr_t)d_m % 16 == 0 && nsig >= 64) {
+        // LDS-tiled form: 128 x 128 tiles on / above the diagonal, the K range split over as many workgroups as there are CUs
+        const int nt = (int)((nsig + cov::CT - 1) / cov::CT), ntri = nt * (nt + 1) / 2, nchunks = blocksize / cov::KC;
+        const int S = std::max(1, std::min(nchunks, device_cus() / ntri));
+        OP_RESERVE(3, sizeof(int) * 3 * cov::CT * cov::CT * (size_t)ntri * (size_t)S);
+        HIP_TRY(hipFuncSetAttribute((const void *)cov::k_covariance_tiled, hipFuncAttributeMaxDynamicSharedMemorySize, cov::COV_LDS_BYTES));
+        hipLaunchKernelGGL(cov::k_covariance_tiled, dim3((unsigned)ntri, (unsigned)S), dim3(256), cov::COV_LDS_BYTES, 0, d_m, nrows, blocksize, nt, (int *)g_op.buf[3]);
+        HIP_TRY(hipGetLastError());
+        hipLaunchKernelGGL(cov::k_cov_reduce, dim3((unsigned)ntri, cov::CT), dim3(cov::CT), 0, 0, (const int *)g_op.buf[3], S, ntri, nt, nrows, blocksize,
+                           (const int2 *)g_op.buf[2], d_r);
+        HIP_TRY(hipGetLastError());
+    } else {
+        const unsigned tiles = (unsigned)((nsig + 63) / 64);
+        hipLaunchKernelGGL(cov::k_covariance, dim3(tiles, tiles), dim3(256), 0, 0, d_m, nrows, blocksize, (const int2 *)g_op.buf[2], d_r);
+        HIP_TRY(hipGetLastError());
+    }
     if (mem_kind == CRSDR_MEM_HOST) HIP_TRY(hipMemcpy(rxx, d_r, rb, hipMemcpyDeviceToHost));
     else HIP_TRY(hipDeviceSynchronize());
     return CRSDR_OK;

@@ -121,3 +121,34 @@ def test_music_chain_matches_the_committed_fixture(b, golden_dir):
     assert np.abs(_projector(vec, k) - g["projector"]).max() < 1e-5
     pm = b.pmusic2d(vec, k, float(g["d"]), int(g["mx"]), int(g["my"]), 40, 40)
     assert np.allclose(pm, g["pm"], rtol=1e-2)
+
+
+def _rxx_reference(rows):
+    """beamformclient/heatmap2d2.cpp:189-199 in exact integer sums (int8 products summed in float64: |sum| <= 2^28) and the fp64 epilogue
+    crsdr_covariance uses: (1/L) sum conj(x_a) x_b - conj(mean_a) mean_b with x = (I + jQ) / 127, rounded once to float."""
+    x = rows[1:].astype(np.float64)
+    I, Q = x[:, 0::2], x[:, 1::2]
+    L = I.shape[1]
+    g1 = I @ I.T + Q @ Q.T
+    g3, g2 = I @ Q.T, Q @ I.T
+    si, sq = I.sum(axis=1), Q.sum(axis=1)
+    scale = 1.0 / (127.0 * 127.0)
+    re = (g1 / L - (np.outer(si, si) + np.outer(sq, sq)) / (L * L)) * scale
+    im = ((g3 - g2) / L - (np.outer(si, sq) - np.outer(sq, si)) / (L * L)) * scale
+    return (re + 1j * im).astype(np.complex64)
+
+
+@pytest.mark.parametrize("nsig,B", [(200, 2048), (64, 128), (1024, 16384), (129, 1024)])
+def test_covariance_lds_tiled_kernel_is_exact(b, nsig, B):
+    # r03: from 64 channels on (and blocksize % 128 == 0) crsdr_covariance runs 128 x 128 output tiles through LDS with the K range split
+    # over the grid, exact int32 partial sums added by a second kernel.  Integer arithmetic: the result must equal the reference
+    # expression evaluated on exact sums, to the one float rounding of the output -- ragged channel counts (200, 129: padded tile rows),
+    # one chunk per block (64 x 128), the benchmark's shape.
+    rng = np.random.default_rng(nsig * 7 + B)
+    rows = rng.integers(-128, 128, size=(nsig + 1, B), dtype=np.int8)
+    rows[3] = -128                                                   # full-scale DC row: the largest sums int32 has to hold
+    rxx = b.covariance(rows)
+    ref = _rxx_reference(rows)
+    assert rxx.shape == ref.shape
+    assert np.abs(rxx - ref).max() <= 2e-7 * np.abs(ref).max()
+    assert np.array_equal(rxx, rxx.conj().T)                         # Hermitian to the bit: the lower triangle is written as the mirror of the upper
