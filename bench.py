@@ -434,7 +434,8 @@ def main():
             b.covariance_device(rxx.data_ptr(), mptr, nrows, B)
         dtc = (time.perf_counter() - t0) / 10
         result["covariance"] = {"ms": 1e3 * dtc, "int8_TOPS": 3 * 2 * nsig * nsig * B / dtc / 1e12,
-                                "note": "Rxx = X^H X / L of the 1024 signal rows, 3 int8 MFMA products, host-synchronous call"}
+                                "note": "Rxx = X^H X / L of the signal rows, host-synchronous call; int8_TOPS counts the full matrix at 3 int8 products "
+                                        "per sample pair as in r01 / r02 (the r03 kernel forms the upper triangle with 2)"}
 
     # ---- extra: host-buffer (PCIe-inclusive) rate -- reported for DESIGN.md, never `value` -----------
     if not args.no_extras and not args.skip_pcie and world == 1:

@@ -611,6 +611,22 @@ extern "C" int crsdr_fft(float *out, const float *in, int n, int sign, int howma
 }
 
 // ---- (iii) downstream helper: sample covariance of the aligned matrix on the matrix cores ----
+// K split of the tiled kernel: the split that minimises rounds-of-workgroups x a tile's time / S + the partial sums' write and read
+// time x S.  A tile's time is what its CU takes to pull the 2 x 128 rows in (measured ~50 GB/s per CU from L2 under the MFMAs; the
+// matrix cores' share, 2 MFMAs per operand pair at 9.8e12 int8 MACs/s per CU, is shorter); the partials move at ~5 TB/s.
+static int cov_pick_split(int ntri, int npairs, int blocksize, int cus)
+{
+    const double mfma_us = 2.0 * cov::CT * cov::CT * (double)blocksize / 9.8e6, ingest_us = 2.0 * cov::CT * (double)blocksize / 5e4;
+    const double tile_us = std::max(mfma_us, ingest_us), part_us = (double)ntri * 2 * cov::CT * cov::CT * 4 * 2 / 5e6;
+    int best = 1;
+    double best_cost = 1e30;
+    for (int s = 1; s <= std::min(npairs, 32); ++s) {
+        const double cost = (double)((ntri * s + cus - 1) / cus) / s * tile_us + s * part_us;
+        if (cost < best_cost) { best_cost = cost; best = s; }
+    }
+    return best;
+}
+
 extern "C" int crsdr_covariance(float *rxx, const int8_t *matrix, int nrows, int blocksize, int mem_kind)
 {
     if (!rxx || !matrix || nrows < 2 || blocksize < 32 || (blocksize % 32)) return fail(CRSDR_EINVAL, "covariance: need rxx, matrix, nrows >= 2, blocksize % 32 == 0");
@@ -620,28 +636,31 @@ extern "C" int crsdr_covariance(float *rxx, const int8_t *matrix, int nrows, int
     const size_t mb = (size_t)nrows * (size_t)blocksize, nsig = (size_t)nrows - 1, rb = sizeof(float2) * nsig * nsig;
     const int8_t *d_m = matrix;
     float2 *d_r = (float2 *)rxx;
-    OP_RESERVE(2, sizeof(int2) * (size_t)nrows);
     if (mem_kind == CRSDR_MEM_HOST) {
         OP_RESERVE(0, mb); OP_RESERVE(1, rb);
         HIP_TRY(hipMemcpy(g_op.buf[0], matrix, mb, hipMemcpyHostToDevice));
         d_m = (const int8_t *)g_op.buf[0];
         d_r = (float2 *)g_op.buf[1];
     }
-    hipLaunchKernelGGL(cov::k_row_sums, dim3(nrows), dim3(256), 0, 0, d_m, blocksize, (int2 *)g_op.buf[2]);
-    HIP_TRY(hipGetLastError());
-    if (blocksize % cov::KC == 0 && (uintptr_t)d_m % 16 == 0 && nsig >= 64) {
-        // LDS-tiled form: 128 x 128 tiles on / above the diagonal, the K range split over as many workgroups as there are CUs
-        const int nt = (int)((nsig + cov::CT - 1) / cov::CT), ntri = nt * (nt + 1) / 2, nchunks = blocksize / cov::KC;
-        const int S = std::max(1, std::min(nchunks, device_cus() / ntri));
-        OP_RESERVE(3, sizeof(int) * 3 * cov::CT * cov::CT * (size_t)ntri * (size_t)S);
+    if (blocksize % (2 * cov::KC) == 0 && (uintptr_t)d_m % 16 == 0 && nsig >= 64) {
+        // LDS-tiled form: 128 x 128 tiles on / above the diagonal, the K range split (in pairs of chunks) over the grid
+        const int nt = (int)((nsig + cov::CT - 1) / cov::CT), ntri = nt * (nt + 1) / 2, npairs = blocksize / (2 * cov::KC);
+        const int S = cov_pick_split(ntri, npairs, blocksize, device_cus());
+        const unsigned grid = 8u * (unsigned)((ntri * S + 7) / 8);
+        OP_RESERVE(2, sizeof(int2) * (size_t)nt * cov::CT * (size_t)S);
+        OP_RESERVE(3, sizeof(int) * 2 * cov::CT * cov::CT * (size_t)ntri * (size_t)S);
         HIP_TRY(hipFuncSetAttribute((const void *)cov::k_covariance_tiled, hipFuncAttributeMaxDynamicSharedMemorySize, cov::COV_LDS_BYTES));
-        hipLaunchKernelGGL(cov::k_covariance_tiled, dim3((unsigned)ntri, (unsigned)S), dim3(256), cov::COV_LDS_BYTES, 0, d_m, nrows, blocksize, nt, (int *)g_op.buf[3]);
+        hipLaunchKernelGGL(cov::k_covariance_tiled, dim3(grid), dim3(cov::COV_THREADS), cov::COV_LDS_BYTES, 0, d_m, nrows, blocksize, nt, ntri, S, (int *)g_op.buf[3],
+                           (int2 *)g_op.buf[2]);
         HIP_TRY(hipGetLastError());
-        hipLaunchKernelGGL(cov::k_cov_reduce, dim3((unsigned)ntri, cov::CT), dim3(cov::CT), 0, 0, (const int *)g_op.buf[3], S, ntri, nt, nrows, blocksize,
-                           (const int2 *)g_op.buf[2], d_r);
+        hipLaunchKernelGGL(cov::k_cov_reduce, dim3((unsigned)ntri, cov::CT / cov::CR), dim3(256), 0, 0, (const int *)g_op.buf[3], (const int2 *)g_op.buf[2], S, ntri, nt,
+                           nrows, blocksize, d_r);
         HIP_TRY(hipGetLastError());
     } else {
         const unsigned tiles = (unsigned)((nsig + 63) / 64);
+        OP_RESERVE(2, sizeof(int2) * (size_t)nrows);
+        hipLaunchKernelGGL(cov::k_row_sums, dim3(nrows), dim3(256), 0, 0, d_m, blocksize, (int2 *)g_op.buf[2]);
+        HIP_TRY(hipGetLastError());
         hipLaunchKernelGGL(cov::k_covariance, dim3(tiles, tiles), dim3(256), 0, 0, d_m, nrows, blocksize, (const int2 *)g_op.buf[2], d_r);
         HIP_TRY(hipGetLastError());
     }
