@@ -265,6 +265,20 @@ extern "C" int crsdr_exchange_create(crsdr_exchange **x, const void *id, int nra
     return CRSDR_OK;
 }
 
+// what crsdr_exchange_bind_plan allocated (all of it, or what a bind that failed half way got as far as)
+static void xengine_release(crsdr_exchange *x)
+{
+    for (int k = 0; k < 2; ++k) {
+        for (int8_t **b : {&x->d_send[k], &x->d_recv[k], &x->d_packets[k], &x->d_scal[k]}) { if (*b) (void)hipFree(*b); *b = nullptr; }
+        if (x->ev_done[k]) (void)hipEventDestroy(x->ev_done[k]);
+        x->ev_done[k] = nullptr; x->done_valid[k] = false;
+    }
+    if (x->ev_sub) (void)hipEventDestroy(x->ev_sub);
+    if (x->xs) (void)hipStreamDestroy(x->xs);
+    if (x->cs) (void)hipStreamDestroy(x->cs);
+    x->ev_sub = nullptr; x->xs = nullptr; x->cs = nullptr;
+}
+
 extern "C" int crsdr_exchange_destroy(crsdr_exchange *x)
 {
     if (!x) return fail(CRSDR_EINVAL, "exchange_destroy: NULL");
@@ -276,13 +290,7 @@ extern "C" int crsdr_exchange_destroy(crsdr_exchange *x)
     }
     if (x->comm) (void)g_rccl.CommDestroy(x->comm);
     if (x->tail_stage) (void)hipFree(x->tail_stage);
-    for (int k = 0; k < 2; ++k) {
-        for (int8_t *b : {x->d_send[k], x->d_recv[k], x->d_packets[k], x->d_scal[k]}) if (b) (void)hipFree(b);
-        if (x->ev_done[k]) (void)hipEventDestroy(x->ev_done[k]);
-    }
-    if (x->ev_sub) (void)hipEventDestroy(x->ev_sub);
-    if (x->xs) (void)hipStreamDestroy(x->xs);
-    if (x->cs) (void)hipStreamDestroy(x->cs);
+    xengine_release(x);
     delete x;
     return CRSDR_OK;
 }
@@ -370,20 +378,24 @@ extern "C" int crsdr_exchange_bind_plan(crsdr_exchange *x, crsdr_plan *plan, int
     x->geo = g; x->xmode = mode;
     x->bpr = (plan->max_batch + x->nranks - 1) / x->nranks;
     x->pstride = (plan->packet_bytes + 255) / 256 * 256;
-    HIP_TRY(hipStreamCreateWithFlags(&x->xs, hipStreamNonBlocking));
-    HIP_TRY(hipStreamCreateWithFlags(&x->cs, hipStreamNonBlocking));
-    HIP_TRY(hipEventCreateWithFlags(&x->ev_sub, hipEventDisableTiming));
-    for (int k = 0; k < 2; ++k) {
-        HIP_TRY(hipEventCreateWithFlags(&x->ev_done[k], hipEventDisableTiming));
-        HIP_TRY(hipMalloc((void **)&x->d_send[k], (size_t)plan->max_batch * g.slot));
-        HIP_TRY(hipMalloc((void **)&x->d_recv[k], (size_t)x->nranks * (size_t)x->bpr * g.slot));
-        HIP_TRY(hipMalloc((void **)&x->d_packets[k], (size_t)x->bpr * x->pstride + 256));
-        HIP_TRY(hipMalloc((void **)&x->d_scal[k], (size_t)x->bpr * g.scalars));
-        HIP_TRY(hipMemset(x->d_packets[k], 0, (size_t)x->bpr * x->pstride + 256));
-        HIP_TRY(hipMemset(x->d_scal[k], 0, (size_t)x->bpr * g.scalars));
-        x->pk_off[k] = (256 - ((uintptr_t)x->d_packets[k] + g.matrix_off) % 256) % 256;      // the matrix of every packet 256-byte aligned
-    }
-    HIP_TRY(hipDeviceSynchronize());
+    const int rc_alloc = [&]() -> int {
+        HIP_TRY(hipStreamCreateWithFlags(&x->xs, hipStreamNonBlocking));
+        HIP_TRY(hipStreamCreateWithFlags(&x->cs, hipStreamNonBlocking));
+        HIP_TRY(hipEventCreateWithFlags(&x->ev_sub, hipEventDisableTiming));
+        for (int k = 0; k < 2; ++k) {
+            HIP_TRY(hipEventCreateWithFlags(&x->ev_done[k], hipEventDisableTiming));
+            HIP_TRY(hipMalloc((void **)&x->d_send[k], (size_t)plan->max_batch * g.slot));
+            HIP_TRY(hipMalloc((void **)&x->d_recv[k], (size_t)x->nranks * (size_t)x->bpr * g.slot));
+            HIP_TRY(hipMalloc((void **)&x->d_packets[k], (size_t)x->bpr * x->pstride + 256));
+            HIP_TRY(hipMalloc((void **)&x->d_scal[k], (size_t)x->bpr * g.scalars));
+            HIP_TRY(hipMemset(x->d_packets[k], 0, (size_t)x->bpr * x->pstride + 256));
+            HIP_TRY(hipMemset(x->d_scal[k], 0, (size_t)x->bpr * g.scalars));
+            x->pk_off[k] = (256 - ((uintptr_t)x->d_packets[k] + g.matrix_off) % 256) % 256;      // the matrix of every packet 256-byte aligned
+        }
+        HIP_TRY(hipDeviceSynchronize());
+        return CRSDR_OK;
+    }();
+    if (rc_alloc) { xengine_release(x); return rc_alloc; }    // (the error text is the failing call's)
     x->plan = plan;
     return CRSDR_OK;
 }

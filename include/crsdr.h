@@ -360,7 +360,10 @@ int crsdr_exchange_submit_batch(crsdr_exchange *x, const void *rows, int mem_kin
  * own_tails: {lag, mag, frac, phasor} of this rank's OWN rows for every block of the batch -- block t at own_tails + t * host_tails_stride
  * as  int32 lag[per] | float mag[per] | float frac[per] | float phasor[per][2]  (20 * per bytes): what csdrdevice::set_lag needs on the
  * process that reads those dongles (src/ccoherent.cc:232-233), whichever rank assembles the block; *nblocks = blocks in the batch.
- * Any pointer may be NULL.  Reports a kernel-side error like crsdr_plan_fetch_wait does (the plan is rolled back). */
+ * Any pointer may be NULL.  Reports a kernel-side error like crsdr_plan_fetch_wait does (the plan is rolled back and what else was
+ * outstanding on THIS rank is dropped).  The ranks' exchange sequences stay matched -- the failing rank's sends of those batches were
+ * issued -- but its peers assembled garbage rows from it: a host that wants the batches back resubmits them on every rank, in the
+ * same order. */
 int crsdr_exchange_fetch_rooted(crsdr_exchange *x, int8_t *packets, size_t host_packet_stride, void *scalars, size_t host_scalars_stride,
                                 void *own_tails, size_t host_tails_stride, int *first, int *count, int *nblocks);
 
