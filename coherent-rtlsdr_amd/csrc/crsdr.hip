@@ -1453,7 +1453,8 @@ extern "C" int crsdr_plan_submit_batch(crsdr_plan *p, const void *rows, int mem_
             p->chain_slot = cs ^ 1;
         }
         {
-            // (two rows per workgroup sharing the reference row's registers: built and measured in r03, 4.05 against 4.85 TB/s -- tools/k2_pair.hpp)
+            // (two rows per workgroup sharing the reference row's registers: built and measured in r03, 4.05 against 4.85 TB/s -- tools/k2_pair.hpp;
+            //  persistent workgroups with the next item's row loads in flight: 3.1 - 3.6 against 4.76 TB/s -- tools/k2_persist.hpp)
             const dim3 grid((unsigned)((1 + p->row_count) * nblocks));
             if (p->B == 16384 && !xor80) hipLaunchKernelGGL((k_align_fused<true, false>), grid, dim3(kAlignThreads), 0, S, aa, fs);
             else if (p->B == 16384) hipLaunchKernelGGL((k_align_fused<true, true>), grid, dim3(kAlignThreads), 0, S, aa, fs);
