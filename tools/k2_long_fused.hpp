@@ -1,7 +1,7 @@
 // tools/k2_long_fused.hpp -- DEAD END 16 (r03), kept for the record; not part of the product.
 // The long rows' phase path (one block per submit) as ONE kernel instead of k_phase_dot + k_align_quant.  Bit-identical to the
 // three-kernel path in a variants test (B = 2^15 ... 2^21, track / locked / no reference noise, also with the wait cut to zero polls),
-// and slower on cfg5 (21 rows x 2 MiB, A/B in one call, gpurun_out of the session: tools/gpu_session_o.sh):
+// and slower on cfg5 (21 rows x 2 MiB, A/B in one call: bench.py --cfg5 with the kernel switched on and off, two rounds):
 //     two kernels                           23.9 + 21.1 = 45 us   2 540 - 2 580 blocks/s
 //     this kernel, 32 KiB chunks (118 VGPRs)        54 us          2 480 - 2 500
 //     this kernel, 16 KiB chunks ( 86 VGPRs)     88 - 91 us        2 270 - 2 290
