@@ -126,6 +126,14 @@ __device__ __forceinline__ void cov_tile_of(int u, int nt, int &ti, int &tj)
     tj = ti + u;
 }
 
+// 16 bytes from a 4-byte aligned address (a packet's matrix starts at 16 + 4 N: the hardware takes a dword-aligned global_load_dwordx4)
+struct __attribute__((packed, aligned(4))) cov_u4 { uint32_t x, y, z, w; };
+__device__ __forceinline__ uint4 cov_load16(const int8_t *p)
+{
+    const cov_u4 u = *reinterpret_cast<const cov_u4 *>(p);
+    return make_uint4(u.x, u.y, u.z, u.w);
+}
+
 __device__ __forceinline__ void cov_iq_sums(const uint4 w, int &si, int &sq)
 {
     si = __builtin_amdgcn_sdot4((int)w.x, 0x00010001, si, false); sq = __builtin_amdgcn_sdot4((int)w.x, 0x01000100, sq, false);
@@ -169,15 +177,15 @@ __global__ __launch_bounds__(COV_THREADS, 1) void k_covariance_tiled(const int8_
 #define COV_GLOAD(P, c)                                                                                              \
     do {                                                                                                             \
         const size_t ko = (size_t)(c) * KC;                                                                          \
-        P##a0 = *reinterpret_cast<const uint4 *>(matrix + oa0 + ko);                                                 \
-        P##a1 = *reinterpret_cast<const uint4 *>(matrix + oa1 + ko);                                                 \
-        P##a2 = *reinterpret_cast<const uint4 *>(matrix + oa2 + ko);                                                 \
-        P##a3 = *reinterpret_cast<const uint4 *>(matrix + oa3 + ko);                                                 \
+        P##a0 = cov_load16(matrix + oa0 + ko);                                                 \
+        P##a1 = cov_load16(matrix + oa1 + ko);                                                 \
+        P##a2 = cov_load16(matrix + oa2 + ko);                                                 \
+        P##a3 = cov_load16(matrix + oa3 + ko);                                                 \
         if (!diag) {                                                                                                 \
-            P##b0 = *reinterpret_cast<const uint4 *>(matrix + ob0 + ko);                                             \
-            P##b1 = *reinterpret_cast<const uint4 *>(matrix + ob1 + ko);                                             \
-            P##b2 = *reinterpret_cast<const uint4 *>(matrix + ob2 + ko);                                             \
-            P##b3 = *reinterpret_cast<const uint4 *>(matrix + ob3 + ko);                                             \
+            P##b0 = cov_load16(matrix + ob0 + ko);                                             \
+            P##b1 = cov_load16(matrix + ob1 + ko);                                             \
+            P##b2 = cov_load16(matrix + ob2 + ko);                                             \
+            P##b3 = cov_load16(matrix + ob3 + ko);                                             \
         }                                                                                                            \
     } while (0)
 #define COV_LSTORE(P, buf)                                                                                           \

@@ -642,7 +642,7 @@ extern "C" int crsdr_covariance(float *rxx, const int8_t *matrix, int nrows, int
         d_m = (const int8_t *)g_op.buf[0];
         d_r = (float2 *)g_op.buf[1];
     }
-    if (blocksize % (2 * cov::KC) == 0 && (uintptr_t)d_m % 16 == 0 && nsig >= 64) {
+    if (blocksize % (2 * cov::KC) == 0 && (uintptr_t)d_m % 4 == 0 && nsig >= 64) {
         // LDS-tiled form: 128 x 128 tiles on / above the diagonal, the K range split (in pairs of chunks) over the grid
         const int nt = (int)((nsig + cov::CT - 1) / cov::CT), ntri = nt * (nt + 1) / 2, npairs = blocksize / (2 * cov::KC);
         const int S = cov_pick_split(ntri, npairs, blocksize, device_cus());

@@ -140,7 +140,7 @@ def _rxx_reference(rows):
 
 @pytest.mark.parametrize("nsig,B", [(200, 2048), (64, 128), (1024, 16384), (129, 1024)])
 def test_covariance_lds_tiled_kernel_is_exact(b, nsig, B):
-    # r03: from 64 channels on (and blocksize % 128 == 0) crsdr_covariance runs 128 x 128 output tiles through LDS with the K range split
+    # r03: from 64 channels on (and blocksize % 512 == 0; B = 128: the one-tile-per-wave kernel) crsdr_covariance runs 128 x 128 output tiles through LDS with the K range split
     # over the grid, exact int32 partial sums added by a second kernel.  Integer arithmetic: the result must equal the reference
     # expression evaluated on exact sums, to the one float rounding of the output -- ragged channel counts (200, 129: padded tile rows),
     # one chunk per block (64 x 128), the benchmark's shape.
@@ -152,3 +152,15 @@ def test_covariance_lds_tiled_kernel_is_exact(b, nsig, B):
     assert rxx.shape == ref.shape
     assert np.abs(rxx - ref).max() <= 2e-7 * np.abs(ref).max()
     assert np.array_equal(rxx, rxx.conj().T)                         # Hermitian to the bit: the lower triangle is written as the mirror of the upper
+    # the matrix where a packet holds it -- 16 + 4 N bytes behind a 256-byte aligned base, i.e. 4-byte aligned only -- on the device:
+    # the same kernels (16-byte loads from dword-aligned addresses), the same bits
+    import torch
+    dev = torch.device("cuda", 0)
+    off = 16 + 4 * (nsig + 1)
+    buf = torch.zeros(off + rows.size + 256, dtype=torch.int8, device=dev)
+    buf[off: off + rows.size].copy_(torch.from_numpy(rows.reshape(-1)))
+    out = torch.zeros((nsig, nsig, 2), dtype=torch.float32, device=dev)
+    assert (buf.data_ptr() + off) % 16 != 0 and (buf.data_ptr() + off) % 4 == 0
+    b.covariance_device(out.data_ptr(), buf.data_ptr() + off, nsig + 1, B)
+    got = out.cpu().numpy().view(np.complex64).reshape(nsig, nsig)
+    assert np.array_equal(got, rxx)
