@@ -156,6 +156,8 @@ def main():
         scal = [torch.zeros(Tg * sstride, dtype=torch.uint8, device=dev) for _ in range(NSETS)]
         xstream = torch.cuda.Stream(device=dev)       # waits for the exchange, then assembles: never blocks the compute stream
         done = [None] * NSETS                          # event: set k's exchange + assembly finished
+        done_pool = [torch.cuda.Event() for _ in range(NSETS)]      # re-recorded per batch (creating one costs the host ~5 us)
+        ready_ev = torch.cuda.Event()
     xchg = {"c": None}                                 # crsdr_exchange (RCCL under the C ABI) when the C transport is selected
 
     gib = {"n": 0, "last_full": None}                  # batches issued so far: output sets, input blocks and seq keep rotating across regions
@@ -190,12 +192,11 @@ def main():
             return
         if xchg["c"] is not None:
             # the same exchange under the C ABI: grouped ncclSend / ncclRecv + assembly, all enqueued on the side stream
-            ready = torch.cuda.Event()
-            ready.record(stream)
-            xstream.wait_event(ready)
+            ready_ev.record(stream)
+            xstream.wait_event(ready_ev)
             xchg["c"].batch(b.XCHG_STAGED, send[k].data_ptr(), recv[k].data_ptr(), nb, pk_view[k][0].data_ptr(), pstride, scal[k].data_ptr(), sstride,
                             nrows, B, xstream.cuda_stream)
-            done[k] = torch.cuda.Event()
+            done[k] = done_pool[k]
             done[k].record(xstream)
             return
         work = sharding.exchange_slots(recv[k], send[k], nb, slot, async_op=True)     # RCCL stream: ordered after the submit above
@@ -204,7 +205,7 @@ def main():
             if len(mine):
                 b.assemble_slots(pk_view[k][0].data_ptr(), pstride, scal[k].data_ptr(), sstride, nrows, B, recv[k].data_ptr(), world, len(mine), slot, toff,
                                  stream=xstream.cuda_stream)
-            done[k] = torch.cuda.Event()
+            done[k] = done_pool[k]
             done[k].record(xstream)
 
     def fence():

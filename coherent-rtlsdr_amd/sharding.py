@@ -156,6 +156,9 @@ def rooted_range(nblocks: int, world: int, rank: int) -> range:
     return range(first, first + min(bpr, nblocks - first))
 
 
+_SPLITS = {}
+
+
 def exchange_slots(recv, send, nblocks: int, slot_stride: int, group=None, async_op: bool = True):
     """ONE all-to-all for a batch of nblocks blocks whose slots carry rows + per-row scalars.
 
@@ -168,10 +171,15 @@ def exchange_slots(recv, send, nblocks: int, slot_stride: int, group=None, async
 
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
-    counts = [len(rooted_range(nblocks, world, q)) for q in range(world)]
-    in_splits = [c * slot_stride for c in counts]
-    out_splits = [counts[rank] * slot_stride] * world
-    return dist.all_to_all_single(recv.view(-1)[: sum(out_splits)], send.view(-1)[: nblocks * slot_stride], out_splits, in_splits,
+    key = (world, rank, nblocks, slot_stride)
+    splits = _SPLITS.get(key)
+    if splits is None:                       # per batch shape, not per batch: this runs on the host's critical path at 8 GPUs
+        counts = [len(rooted_range(nblocks, world, q)) for q in range(world)]
+        in_splits = [c * slot_stride for c in counts]
+        out_splits = [counts[rank] * slot_stride] * world
+        splits = _SPLITS[key] = (in_splits, out_splits, sum(out_splits))
+    in_splits, out_splits, total_out = splits
+    return dist.all_to_all_single(recv.view(-1)[:total_out], send.view(-1)[: nblocks * slot_stride], out_splits, in_splits,
                                   group=group, async_op=async_op)
 
 
