@@ -139,7 +139,7 @@ def main():
         plan.set_frac_apply(True, 1.0, None)
     # NSETS ring-buffered output sets (the exchange of batch i runs under the compute of batch i+1); the matrix
     # of every packet is 16-byte aligned.  One GPU: T packets per set.  Several GPUs: per set one slot buffer
-    # [T][slot_stride] (rows + the 20 B/row {lag, mag, frac, phasor} tail of the rank's slab: the all-to-all's send side),
+    # [T][slot_stride] (rows + the 24 B/row {lag, mag, frac, phasor, readcnt} tail of the rank's slab: the all-to-all's send side),
     # one receive buffer [G][Tg][slot_stride], the Tg = ceil(T/G) packets this rank assembles and their scalars blocks.
     NSETS = 3 if multi else 2
     Tg = -(-T // world)
@@ -364,7 +364,7 @@ def main():
                                    f"{nbuf} rotating input blocks, {T} blocks per submit",
                        "rows": nrows, "L": L, "fft_len": B, "mode": args.mode, "batch": T,
                        "forced_exchange_path": force_x,
-                       "parallelism": f"rows sharded x{world}, ref replicated, rotating-root gather of int8 rows + 20 B/row {{lag, mag, frac, phasor}}: one RCCL all-to-all per {T}-block batch + local assembly, overlapped with the next batch" if world > 1 else "single GPU"},
+                       "parallelism": f"rows sharded x{world}, ref replicated, rotating-root gather of int8 rows + 24 B/row {{lag, mag, frac, phasor, readcnt}}: one RCCL all-to-all per {T}-block batch + local assembly, overlapped with the next batch" if world > 1 else "single GPU"},
             "roofline": {"bound": "hbm", "kernel": "k_xcorr_lag", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": _committed_traffic("k_xcorr_lag", tb)[0],
                          "traffic_source": _committed_traffic("k_xcorr_lag", tb)[1],

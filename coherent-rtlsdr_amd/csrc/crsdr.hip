@@ -1173,11 +1173,12 @@ extern "C" int crsdr_plan_set_frac_apply(crsdr_plan *p, int enable, float gain, 
 }
 
 // slab mode with tails (crsdr_plan_bind_slab_ex): {lag, mag, frac, phasor} of the owned rows behind the rows of every slot
-static int pack_tails(crsdr_plan *p, hipStream_t S, int nblocks, const int32_t *o_lag, const float *o_mag, const float *o_frac)
+static int pack_tails(crsdr_plan *p, hipStream_t S, int nblocks, const int32_t *o_lag, const float *o_mag, const float *o_frac, const uint32_t *d_readcnt,
+                      uint32_t seq)
 {
     if (!p->d_slab || !p->tail_offset) return CRSDR_OK;
     hipLaunchKernelGGL(k_pack_tails, dim3((unsigned)((p->row_count + 255) / 256), (unsigned)nblocks), dim3(256), 0, S, p->d_slab, p->slab_stride, p->tail_offset,
-                       p->row_begin, p->row_count, p->nrows, o_lag, o_mag, o_frac, p->d_phasor);
+                       p->row_begin, p->row_count, p->nrows, o_lag, o_mag, o_frac, p->d_phasor, d_readcnt, seq);
     HIP_TRY(hipGetLastError());
     return CRSDR_OK;
 }
@@ -1468,7 +1469,7 @@ extern "C" int crsdr_plan_submit_batch(crsdr_plan *p, const void *rows, int mem_
             HIP_TRY(CRSDR_DISPATCH_LOG2(p->log2n, (launch_frac_apply<LG>(S, p->row_count, nblocks, fa, p->d_tw))));
         }
         if (pe) HIP_TRY(hipEventRecord(pe[1], S));
-        { int rc_ = pack_tails(p, S, nblocks, o_lag, o_mag, o_frac); if (rc_) return rc_; }
+        { int rc_ = pack_tails(p, S, nblocks, o_lag, o_mag, o_frac, d_readcnt, seq); if (rc_) return rc_; }
         HIP_TRY(hipEventRecord(p->ev_k2done[obuf], S));
         p->k2done_valid[obuf] = true;
         p->fused_used = true;
@@ -1538,7 +1539,7 @@ extern "C" int crsdr_plan_submit_batch(crsdr_plan *p, const void *rows, int mem_
         }
         if (pe) HIP_TRY(hipEventRecord(pe[1], S));
     }
-    { int rc_ = pack_tails(p, S, nblocks, o_lag, o_mag, o_frac); if (rc_) return rc_; }
+    { int rc_ = pack_tails(p, S, nblocks, o_lag, o_mag, o_frac, d_readcnt, seq); if (rc_) return rc_; }
     HIP_TRY(hipEventRecord(p->ev_k2done[obuf], S));
     p->k2done_valid[obuf] = true;
     p->phase_cur = pout;

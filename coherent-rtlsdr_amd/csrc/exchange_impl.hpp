@@ -9,7 +9,7 @@ namespace {
 struct XGeo {
     int per = 0;               // signal rows per rank
     size_t rows_bytes = 0;     // per * B
-    size_t tail_bytes = 0;     // 20 * per: lag i32 | mag f32 | frac f32 | phasor 2 x f32
+    size_t tail_bytes = 0;     // 24 * per: lag i32 | mag f32 | frac f32 | phasor 2 x f32 | readcnt u32
     size_t tail_slot = 0;      // tail_bytes rounded up to 16 (stride of the in-place mode's tail staging)
     size_t slot = 0;           // rows_bytes + tail_bytes rounded up to 16
     size_t scalars = 0;        // 20 * nrows rounded up to 16
@@ -23,7 +23,7 @@ int xgeo(int nrows, int B, int nranks, XGeo *g)
     if (nrows < 2 || B < 16 || nranks < 1 || (nrows - 1) % nranks) return fail(CRSDR_EINVAL, "exchange: %d signal rows do not split evenly over %d ranks", nrows - 1, nranks);
     g->per = (nrows - 1) / nranks;
     g->rows_bytes = (size_t)g->per * (size_t)B;
-    g->tail_bytes = 20 * (size_t)g->per;
+    g->tail_bytes = 24 * (size_t)g->per;
     g->tail_slot = up16(g->tail_bytes);
     g->slot = up16(g->rows_bytes + g->tail_bytes);
     g->scalars = up16(20 * (size_t)nrows);
@@ -171,9 +171,9 @@ extern "C" int crsdr_plan_bind_slab_ex(crsdr_plan *p, void *device_slab, size_t 
     if (rc) return rc;
     p->tail_offset = 0;
     if (!device_slab || tail_offset == 0) return CRSDR_OK;
-    if (tail_offset % 4 || tail_offset < (size_t)p->row_count * (size_t)p->B || tail_offset + 20 * (size_t)p->row_count > slab_stride) {
+    if (tail_offset % 4 || tail_offset < (size_t)p->row_count * (size_t)p->B || tail_offset + 24 * (size_t)p->row_count > slab_stride) {
         (void)crsdr_plan_bind_slab(p, nullptr, 0, 0, 0);
-        return fail(CRSDR_EINVAL, "plan_bind_slab_ex: tail_offset must be 4-byte aligned, >= row_count*blocksize, and leave 20 bytes per owned row inside the slot");
+        return fail(CRSDR_EINVAL, "plan_bind_slab_ex: tail_offset must be 4-byte aligned, >= row_count*blocksize, and leave 24 bytes per owned row inside the slot");
     }
     p->tail_offset = tail_offset;
     return CRSDR_OK;

@@ -902,12 +902,14 @@ __global__ void k_assemble_slabs(int8_t *packets, size_t packet_stride, size_t b
 
 // ---- exchange slots (the gather carries int8 rows PLUS {lag, mag, frac, phasor} per row) ------------
 // A sharded plan in slab mode writes block t of a batch into the slot  slab + t*slab_stride:
-//   [row_count][B] int8 rows | tail at +tail_offset:  int32 lag[rc] | float mag[rc] | float frac[rc] | float2 phasor[rc]
-// (20 bytes per owned row -- what set_lag (src/ccoherent.cc:232-233) and the port-5557 payload (src/cpacketizer.cc:127,
-// 131-134) consume on the assembling side).  The rows come from the phase kernels; the tail is packed here, after them.
+//   [row_count][B] int8 rows | tail at +tail_offset:  int32 lag[rc] | float mag[rc] | float frac[rc] | float2 phasor[rc] | uint32 readcnt[rc]
+// (24 bytes per owned row -- what set_lag (src/ccoherent.cc:232-233), the port-5557 payload (src/cpacketizer.cc:127, 131-134) and the
+// packet header's read counters (src/cpacketizer.cc:142,163: each device's own block count, what clients detect drops by) consume on
+// the assembling side: the rank that READS a dongle is the one that knows its counter).  The rows come from the phase kernels; the tail
+// is packed here, after them.
 __global__ void k_pack_tails(int8_t *slab, size_t slab_stride, size_t tail_offset, int row_begin, int row_count, int nrows,
                              const int32_t *__restrict__ lag, const float *__restrict__ mag, const float *__restrict__ frac,
-                             const float2 *__restrict__ phasor)
+                             const float2 *__restrict__ phasor, const uint32_t *__restrict__ readcnt, uint32_t seq)
 {
     const int t = blockIdx.y, i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= row_count) return;
@@ -919,12 +921,15 @@ __global__ void k_pack_tails(int8_t *slab, size_t slab_stride, size_t tail_offse
     const float2 ph = phasor[o];                              // written as two floats: 12*rc need not be 8-byte aligned
     reinterpret_cast<float *>(tail + 12 * (size_t)row_count)[2 * i] = ph.x;
     reinterpret_cast<float *>(tail + 12 * (size_t)row_count)[2 * i + 1] = ph.y;
+    reinterpret_cast<uint32_t *>(tail + 20 * (size_t)row_count)[i] = readcnt ? readcnt[o] : seq + (uint32_t)t;      // as the header kernels fill it
 }
 
 // On the assembling rank: slots [nsrc][nblocks][slot_stride] (what the exchange delivers: chunk z = rank (src_base + z)'s slots
 // of the nblocks blocks assembled here; the rank's own chunk may be read straight from its send buffer: self_src) ->
 //   rows  -> matrix rows 1 + src*per .. of packet j            (unless rows_in_place: they already landed there)
 //   tails -> scalars block j:  int32 lag[nrows] | float mag[nrows] | float frac[nrows] | float phasor[nrows][2]  (row 0: zeros)
+//         -> the read counters of the source rank's rows in packet j's header (the assembling rank's own plan wrote the header from
+//            ITS counters: right for row 0 and its own rows, whatever it knew for the others)
 // grid (chunks, nblocks, nsrc); W = uint4 (16-byte aligned everything) or uint32_t.
 template <typename W>
 __global__ void k_assemble_slots(int8_t *packets, size_t packet_stride, size_t body_off, int8_t *scalars, size_t scalars_stride, int nrows, int per, int B,
@@ -941,10 +946,13 @@ __global__ void k_assemble_slots(int8_t *packets, size_t packet_stride, size_t b
         W *d = reinterpret_cast<W *>(packets + (size_t)j * packet_stride + body_off + (size_t)src * per * B);
         for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < words; i += (size_t)gridDim.x * blockDim.x) d[i] = s[i];
     }
-    if (scalars && has_tail && blockIdx.x == 0) {
+    if (has_tail && blockIdx.x == 0) {
         const int8_t *tail = slot + tail_offset;
-        int8_t *out = scalars + (size_t)j * scalars_stride;
         const size_t n = (size_t)nrows, r0 = 1 + (size_t)src * per;
+        uint32_t *hdr_cnt = reinterpret_cast<uint32_t *>(packets + (size_t)j * packet_stride + 16);      // hdr0 is 16 bytes, then uint32 readcnt[N]
+        for (int i = threadIdx.x; i < per; i += blockDim.x) hdr_cnt[r0 + i] = reinterpret_cast<const uint32_t *>(tail + 20 * (size_t)per)[i];
+        if (!scalars) return;
+        int8_t *out = scalars + (size_t)j * scalars_stride;
         for (int i = threadIdx.x; i < per; i += blockDim.x) {
             reinterpret_cast<int32_t *>(out)[r0 + i] = reinterpret_cast<const int32_t *>(tail)[i];
             reinterpret_cast<float *>(out + 4 * n)[r0 + i] = reinterpret_cast<const float *>(tail + 4 * (size_t)per)[i];

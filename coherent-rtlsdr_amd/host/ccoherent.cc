@@ -91,7 +91,7 @@ bool ccoherent::enable_batching(int T)
         bmask[i].assign(n, 0);
         if (xchg) {
             sstride = (20 * n + 15) / 16 * 16;
-            tstride = (20 * (size_t)per + 15) / 16 * 16;
+            tstride = (24 * (size_t)per + 15) / 16 * 16;      // {lag, mag, frac, phasor, readcnt} of this rank's rows
             if (crsdr_host_alloc((void **)&bscal[i], Tz * sstride) != CRSDR_OK || crsdr_host_alloc((void **)&btails[i], Tz * tstride) != CRSDR_OK) {
                 std::fprintf(stderr, "ccoherent: %s\n", crsdr_last_error());
                 return false;

@@ -140,12 +140,12 @@ def rooted_blocks(T: int, world: int, rank: int) -> range:
 
 def slot_geometry(nrows: int, B: int, world: int) -> dict:
     """Send-slot geometry of include/crsdr.h (crsdr_exchange_geometry), restated so that CPU-only code can use it:
-    a slot = [per][B] int8 rows | tail: int32 lag[per] | float mag[per] | float frac[per] | float phasor[per][2]."""
+    a slot = [per][B] int8 rows | tail: int32 lag[per] | float mag[per] | float frac[per] | float phasor[per][2] | uint32 readcnt[per]."""
     per = (nrows - 1) // world
     if per * world != nrows - 1:
         raise ValueError(f"{nrows - 1} signal rows do not split evenly over {world} ranks")
     up16 = lambda v: (v + 15) // 16 * 16
-    return {"per": per, "tail_offset": per * B, "slot_stride": up16(per * B + 20 * per), "scalars_stride": up16(20 * nrows)}
+    return {"per": per, "tail_offset": per * B, "slot_stride": up16(per * B + 24 * per), "scalars_stride": up16(20 * nrows)}
 
 
 def rooted_range(nblocks: int, world: int, rank: int) -> range:

@@ -273,17 +273,18 @@ int crsdr_assemble_slabs(void *device_packets, size_t packet_stride, int nrows, 
                          int nblocks, void *hip_stream);
 
 /* ---- exchange slots: rows + per-row scalars, one message per peer -------------------------------------
- * The gather of SURVEY 8e carries the int8 rows PLUS 20 bytes per row of {lag, mag, frac, phasor}: what
- * csdrdevice::set_lag (src/ccoherent.cc:232-233) and the port-5557 debug payload (src/cpacketizer.cc:127,131-134)
- * consume on the assembling side.  crsdr_plan_bind_slab_ex is crsdr_plan_bind_slab with a TAIL per block: block t of a
+ * The gather of SURVEY 8e carries the int8 rows PLUS 24 bytes per row of {lag, mag, frac, phasor, readcnt}: what
+ * csdrdevice::set_lag (src/ccoherent.cc:232-233), the port-5557 debug payload (src/cpacketizer.cc:127,131-134) and the packet
+ * header's per-device read counters (src/cpacketizer.cc:142,163) consume on the assembling side -- a rank need only know the
+ * counters of row 0 and of the rows it owns.  crsdr_plan_bind_slab_ex is crsdr_plan_bind_slab with a TAIL per block: block t of a
  * batch goes to the slot  device_slab + t*slab_stride =
- *     [row_count][blocksize] int8 rows | at +tail_offset:  int32 lag[rc] | float mag[rc] | float frac[rc] | float phasor[rc][2]
- * (tail_offset >= row_count*blocksize, 4-byte aligned, tail_offset + 20*row_count <= slab_stride; 0 = no tail).  A rank's
+ *     [row_count][blocksize] int8 rows | at +tail_offset:  int32 lag[rc] | float mag[rc] | float frac[rc] | float phasor[rc][2] | uint32 readcnt[rc]
+ * (tail_offset >= row_count*blocksize, 4-byte aligned, tail_offset + 24*row_count <= slab_stride; 0 = no tail).  A rank's
  * slots of the blocks rooted on one peer are consecutive, so they travel as ONE message whatever the block count. */
 int crsdr_plan_bind_slab_ex(crsdr_plan *plan, void *device_slab, size_t slab_stride, int hdr_first, int hdr_count, size_t tail_offset);
 
 /* Slot geometry both sides of an exchange agree on (pure arithmetic, no device needed):
- *   per = (nrows-1)/nranks rows per rank;  tail_offset = per*blocksize;  slot_stride = tail_offset + 20*per rounded up to 16;
+ *   per = (nrows-1)/nranks rows per rank;  tail_offset = per*blocksize;  slot_stride = tail_offset + 24*per rounded up to 16;
  *   scalars_stride = 20*nrows rounded up to 16 (one assembled scalars block per packet, layout below). */
 int crsdr_exchange_geometry(int nrows, int blocksize, int nranks, size_t *slot_stride, size_t *tail_offset, size_t *scalars_stride);
 
@@ -297,6 +298,8 @@ int crsdr_exchange_rooted_blocks(int nblocks, int nranks, int rank, int *first, 
  * device_packets + j*packet_stride;  tails into the scalars block j at device_scalars + j*scalars_stride =
  *     int32 lag[nrows] | float mag[nrows] | float frac[nrows] | float phasor[nrows][2]      (row 0: zeros, like crsdr_plan_fetch;
  *     the phasor part is the N x complex<float> port-5557 payload as is)
+ * and, whenever the slots have tails, the read counters of rank src's rows into packet j's header (uint32 readcnt[N] at +16): the header
+ * the assembling rank's own plan wrote holds ITS view of every counter, right for row 0 and its own rows.
  * self_rank >= 0 with device_self != NULL: that rank's chunk is read from device_self (its own send slots) instead of recv.
  * device_scalars may be NULL.  Asynchronous on hip_stream.  Replaces crsdr_assemble_slabs when tails travel with the rows. */
 int crsdr_assemble_slots(void *device_packets, size_t packet_stride, void *device_scalars, size_t scalars_stride, int nrows, int blocksize,
@@ -317,7 +320,7 @@ int crsdr_exchange_destroy(crsdr_exchange *x);
 enum {
     CRSDR_XCHG_STAGED = 0,   /* one message per peer into device_recv, then crsdr_assemble_slots (what an all-to-all does) */
     CRSDR_XCHG_INPLACE = 1   /* rows land straight in the packet matrix (one message per block and peer, no assembly copy
-                                of remote rows); only the 20 B/row tails go through a small staging buffer */
+                                of remote rows); only the 24 B/row tails go through a small staging buffer */
 };
 /* One batch of nblocks blocks (every rank calls it with the same nblocks / mode, after the submit that filled device_send on
  * hip_stream): rank q = root of blocks [q*bpr, ...) receives every rank's slots of those blocks; on return (stream order) the
@@ -331,7 +334,7 @@ int crsdr_exchange_batch(crsdr_exchange *x, int mode, const void *device_send, v
 /* The point-to-point operations crsdr_exchange_batch issues for (nranks, rank, nblocks, mode), in issue order -- pure host
  * arithmetic, exported so that the matching of every send with its receive can be checked without GPUs (tests simulate the
  * ranks and pair each rank's sends to a peer with that peer's receives from it, first in first out, as RCCL does).
- * buffer: 0 = device_send, 1 = device_recv, 2 = device_packets, 3 = the exchange's tail staging ([nranks][bpr][20*per rounded to 16]). */
+ * buffer: 0 = device_send, 1 = device_recv, 2 = device_packets, 3 = the exchange's tail staging ([nranks][bpr][24*per rounded to 16]). */
 typedef struct crsdr_xop {
     int32_t peer;      /* the other rank */
     int32_t is_recv;   /* 0 = send, 1 = receive */
@@ -358,7 +361,7 @@ int crsdr_exchange_submit_batch(crsdr_exchange *x, const void *rows, int mem_kin
  * of the batch (crsdr_exchange_rooted_blocks; count may be 0) -- packet j at packets + j * host_packet_stride, its scalars block
  * (int32 lag[N] | float mag[N] | float frac[N] | float phasor[N][2], 20 * nrows bytes) at scalars + j * host_scalars_stride.
  * own_tails: {lag, mag, frac, phasor} of this rank's OWN rows for every block of the batch -- block t at own_tails + t * host_tails_stride
- * as  int32 lag[per] | float mag[per] | float frac[per] | float phasor[per][2]  (20 * per bytes): what csdrdevice::set_lag needs on the
+ * as  int32 lag[per] | float mag[per] | float frac[per] | float phasor[per][2] | uint32 readcnt[per]  (24 * per bytes): what csdrdevice::set_lag needs on the
  * process that reads those dongles (src/ccoherent.cc:232-233), whichever rank assembles the block; *nblocks = blocks in the batch.
  * Any pointer may be NULL.  Reports a kernel-side error like crsdr_plan_fetch_wait does (the plan is rolled back and what else was
  * outstanding on THIS rank is dropped).  The ranks' exchange sequences stay matched -- the failing rank's sends of those batches were

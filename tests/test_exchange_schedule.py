@@ -25,7 +25,7 @@ def b():
 def _simulate(b, G, nblocks, mode, nrows, B):
     geo = b.exchange_geometry(nrows, B, G)
     slot, tail_off, per = geo["slot_stride"], geo["tail_offset"], geo["per"]
-    tail_bytes, tail_slot = 20 * per, (20 * per + 15) // 16 * 16
+    tail_bytes, tail_slot = 24 * per, (24 * per + 15) // 16 * 16
     moff = 16 + 4 * nrows
     pstride = (moff + nrows * B + 255) // 256 * 256
     rng = np.random.default_rng(G * 1000 + nblocks)
@@ -92,7 +92,7 @@ def test_cfg4_geometry_and_rooting_match_sharding_py(b):
         for k in ("per", "tail_offset", "slot_stride", "scalars_stride"):
             assert g[k] == s[k], (nrows, B, G, k)
     g = b.exchange_geometry(1025, 16384, 8)
-    assert g["per"] == 128 and g["tail_offset"] == 128 * 16384 and g["slot_stride"] == 128 * 16384 + 2560 and g["scalars_stride"] >= 20 * 1025
+    assert g["per"] == 128 and g["tail_offset"] == 128 * 16384 and g["slot_stride"] == 128 * 16384 + 3072 and g["scalars_stride"] >= 20 * 1025
     for nb in (1, 4, 8, 20, 64):
         for G in (1, 2, 4, 8):
             got = [b.rooted_blocks(nb, G, q) for q in range(G)]

@@ -1,6 +1,6 @@
 """GPU: the multi-GPU exchange of SURVEY 8e on ONE device.
 
-  * G sharded plans in slot mode (crsdr_plan_bind_slab_ex: owned rows + the 20 B/row tail {lag, mag, frac, phasor}); the
+  * G sharded plans in slot mode (crsdr_plan_bind_slab_ex: owned rows + the 24 B/row tail {lag, mag, frac, phasor, readcnt}); the
     transport is emulated by executing every rank's crsdr_exchange_schedule with device copies (sends paired with the
     peer's receives first in first out, as RCCL pairs them); crsdr_assemble_slots then builds the packets and the scalars
     blocks.  Every assembled packet must equal the packet of an unsharded plan bit for bit, every scalars block its
@@ -51,12 +51,21 @@ def test_slots_with_tails_through_the_schedule_equal_the_single_plan(b, synth, G
     ops = [b.exchange_schedule(G, q, T, b.XCHG_STAGED, nrows, B, pstride) for q in range(G)]
     for half in range(2):
         d_in = torch.from_numpy(blocks[half * T:(half + 1) * T].view(np.uint8)).to(dev)
-        full.submit(d_in.data_ptr(), seq=10 + half * T, nblocks=T, block_stride=nrows * B)
+        # per-device read counters (src/cpacketizer.cc:142,163): the unsharded plan is given all of them; a sharded plan only those of
+        # row 0 and of the rows it owns -- garbage for the rest, as in a process that reads only its own dongles -- in the first half,
+        # none at all (seq + t everywhere) in the second.  The assembled headers must equal the unsharded plan's either way.
+        rc_true = (1000 * half + 7 * np.arange(T)[:, None] + 13 * np.arange(nrows)[None, :]).astype(np.uint32) if half == 0 else None
+        full.submit(d_in.data_ptr(), readcnt=rc_true, seq=10 + half * T, nblocks=T, block_stride=nrows * B)
         exp = [full.fetch(block=t) for t in range(T)]
         for r, pl in enumerate(plans):
+            rc_r = None
+            if rc_true is not None:
+                rc_r = np.full_like(rc_true, 0xDEAD0000 + r)
+                rc_r[:, 0] = rc_true[:, 0]
+                rc_r[:, 1 + r * per: 1 + (r + 1) * per] = rc_true[:, 1 + r * per: 1 + (r + 1) * per]
             pl.bind_packet(pk[r].data_ptr() + off[r], pstride)
             pl.bind_slab_ex(send[r].data_ptr(), slot, roots[r].start, len(roots[r]), toff)
-            pl.submit(d_in.data_ptr(), seq=10 + half * T, nblocks=T, block_stride=nrows * B)
+            pl.submit(d_in.data_ptr(), readcnt=rc_r, seq=10 + half * T, nblocks=T, block_stride=nrows * B)
             pl.sync()
         for a in range(G):                                    # the transport: a's sends to c meet c's receives from a in order
             for c in range(G):

@@ -145,7 +145,7 @@ def _worker_a2a(rank, world, port, nsig, L, T, outdir):
 
 
 def _worker_slots(rank, world, port, nsig, L, T, outdir):
-    """The exchange bench.py runs: slots = owned rows + the 20 B/row tail {lag, mag, frac, phasor} (what set_lag and the
+    """The exchange bench.py runs: slots = owned rows + the 24 B/row tail {lag, mag, frac, phasor, readcnt} (what set_lag and the
     port-5557 payload need on the assembling rank, src/ccoherent.cc:232-233, src/cpacketizer.cc:127), ONE all-to-all with
     per-peer split sizes (a ragged batch ships only its own bytes), then assembly by the index contract of
     crsdr_assemble_slots (restated in numpy here; the kernel itself is tested on the GPU against the same contract)."""
@@ -172,13 +172,18 @@ def _worker_slots(rank, world, port, nsig, L, T, outdir):
     packets = {}
     for t in range(T):
         rows, _ = synth.make_block(nsig, L, 58, t, params=params)
-        out = eng.block(rows, seq=t, lag_mask=mask)
+        # this rank knows the read counters of row 0 and of its own rows only (a process that reads its own dongles)
+        rc_true = (500 + 3 * t + 11 * np.arange(nrows)).astype(np.uint32)
+        rc = np.full(nrows, 0xBAD00000 + rank, dtype=np.uint32)
+        rc[0], rc[own] = rc_true[0], rc_true[own]
+        out = eng.block(rows, seq=t, lag_mask=mask, readcnt=rc)
         s = send[t * slot: (t + 1) * slot]
         s[:per * B] = out["matrix"][own].reshape(-1).view(np.uint8)
         s[toff: toff + 4 * per] = out["lag"][own].view(np.uint8)
         s[toff + 4 * per: toff + 8 * per] = out["mag"][own].view(np.uint8)
         s[toff + 8 * per: toff + 12 * per] = out["frac"][own].view(np.uint8)
         s[toff + 12 * per: toff + 20 * per] = out["phasor"][own].view(np.uint8)
+        s[toff + 20 * per: toff + 24 * per] = rc[own].view(np.uint8)
         if t in mine:                                                          # header + readcnt + row 0 only where rooted
             pkt = out["packet"].copy()
             pkt[16 + 4 * nrows + B:] = 99
@@ -197,6 +202,7 @@ def _worker_slots(rank, world, port, nsig, L, T, outdir):
             m[rr] = sl[:per * B].view(np.int8).reshape(per, B)
             lag[rr], mag[rr] = sl[toff: toff + 4 * per].view(np.int32), sl[toff + 4 * per: toff + 8 * per].view(np.float32)
             frac[rr], ph[rr] = sl[toff + 8 * per: toff + 12 * per].view(np.float32), sl[toff + 12 * per: toff + 20 * per].view(np.complex64)
+            packets[t][16:16 + 4 * nrows].view(np.uint32)[rr] = sl[toff + 20 * per: toff + 24 * per].view(np.uint32)      # the header's counters
         np.savez(os.path.join(outdir, f"slot_{t}.npz"), packet=packets[t], lag=lag, mag=mag, frac=frac, phasor=ph)
     dist.barrier()
     dist.destroy_process_group()
@@ -211,7 +217,7 @@ def test_slot_exchange_carries_rows_and_per_row_scalars(world, T, tmp_path, orac
     eng = oracle.Engine(nsig + 1, 2 * L, oracle.DIGITAL)
     for t in range(T):
         rows, _ = synth.make_block(nsig, L, 58, t, params=params)
-        exp = eng.block(rows, seq=t)
+        exp = eng.block(rows, seq=t, readcnt=(500 + 3 * t + 11 * np.arange(nsig + 1)).astype(np.uint32))
         got = np.load(tmp_path / f"slot_{t}.npz")
         assert np.array_equal(got["packet"], exp["packet"]), t
         for k in ("lag", "mag", "frac", "phasor"):
