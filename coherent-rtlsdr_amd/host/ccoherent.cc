@@ -115,9 +115,15 @@ bool ccoherent::fill_batch(int slot, int nblocks, const std::function<void(int)>
         refdev->consume();
         int c = 1;
         for (auto *d : *devices) {                                            // :262-283
-            std::memcpy(dst + (size_t)c * blocksize, d->read(), blocksize);
-            rc[c] = d->get_readcntbuf();                                      // :278 -- what clients detect dropped blocks by (README.md:42)
-            if (d->is_lagrequested()) bmask[slot][c] = 1;                     // :266 -- a request made during the batch is served for the whole batch
+            // sharded: this process hands the plan row 0 and ITS rows only (the plan uploads nothing else, and the other rows' read
+            // counters reach the packet header with their owners' tails); every ring is still drained
+            const bool own = !xchg || (c >= row_begin && c < row_begin + per);
+            const int8_t *src = d->read();
+            if (own) {
+                std::memcpy(dst + (size_t)c * blocksize, src, blocksize);
+                rc[c] = d->get_readcntbuf();                                  // :278 -- what clients detect dropped blocks by (README.md:42)
+                if (d->is_lagrequested()) bmask[slot][c] = 1;                 // :266 -- a request made during the batch is served for the whole batch
+            }
             d->consume();                                                     // :281
             ++c;
         }
