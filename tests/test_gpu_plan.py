@@ -848,3 +848,40 @@ def test_rotate_quantise_saturates_like_convto8bit(b, oracle):
         sat += int(np.count_nonzero((exp == 127) | (exp == -128)))
     assert sat > 50                                   # the case really saturates
     plan.close()
+
+
+def test_two_plans_driven_from_two_threads_equal_their_serial_runs(b, synth):
+    # the G ranks of a node may be G threads of ONE process, each with its own plan (+ exchange).  Two plans of different
+    # shapes on the same device, driven concurrently from two host threads (ctypes releases the GIL inside the library: the calls really
+    # overlap), must give bit for bit what each gives alone: no state shared between plans, errors are per thread.
+    import threading
+    shapes = [(48, 8192, 8, 901), (21, 1024, 5, 902)]          # (nsig, L, T, seed): the 16384-point kernels and a generic size
+    data = []
+    for nsig, L, T, seed in shapes:
+        params = synth.RowParams(nsig, L, seed, dmax=L // 8)
+        data.append(np.stack([synth.make_block(nsig, L, seed, t, params=params)[0] for t in range(3 * T)]))
+
+    def run(k, out):
+        nsig, L, T, _ = shapes[k]
+        plan = b.Plan(nsig + 1, 2 * L, b.MODE_DIGITAL, max_batch=T)
+        res = []
+        for rep in range(3):
+            plan.submit(data[k][rep * T:(rep + 1) * T], seq=rep * T, flags=b.REFNOISE_ENABLED | (b.NO_LAG if rep == 2 else 0))
+            res += [plan.fetch(block=t) for t in range(T)]
+        plan.close()
+        out[k] = res
+
+    serial, conc = {}, {}
+    for k in range(2):
+        run(k, serial)
+    for _ in range(3):                                           # a few rounds: different interleavings
+        th = [threading.Thread(target=run, args=(k, conc)) for k in range(2)]
+        for t_ in th:
+            t_.start()
+        for t_ in th:
+            t_.join()
+        for k in range(2):
+            assert len(conc[k]) == len(serial[k])
+            for got, exp in zip(conc[k], serial[k]):
+                for key in ("lag", "mag", "frac", "phasor", "packet"):
+                    assert np.array_equal(got[key].view(np.uint8), exp[key].view(np.uint8)), (k, key)
