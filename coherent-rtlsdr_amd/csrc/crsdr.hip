@@ -618,9 +618,11 @@ static int cov_pick_split(int ntri, int npairs, int blocksize, int cus)
 {
     const double mfma_us = 2.0 * cov::CT * cov::CT * (double)blocksize / 9.8e6, ingest_us = 2.0 * cov::CT * (double)blocksize / 5e4;
     const double tile_us = std::max(mfma_us, ingest_us), part_us = (double)ntri * 2 * cov::CT * cov::CT * 4 * 2 / 5e6;
-    int best = 1;
+    // a workgroup's int32 partial sums are exact while its K range is <= 65536 bytes (|sum| <= 32768 samples x 2 x 128^2 = 2^30)
+    const int s_min = std::max(1, (blocksize + 65535) / 65536);
+    int best = s_min;
     double best_cost = 1e30;
-    for (int s = 1; s <= std::min(npairs, 32); ++s) {
+    for (int s = s_min; s <= std::max(s_min, std::min(npairs, 32)); ++s) {
         const double cost = (double)((ntri * s + cus - 1) / cus) / s * tile_us + s * part_us;
         if (cost < best_cost) { best_cost = cost; best = s; }
     }
@@ -642,7 +644,11 @@ extern "C" int crsdr_covariance(float *rxx, const int8_t *matrix, int nrows, int
         d_m = (const int8_t *)g_op.buf[0];
         d_r = (float2 *)g_op.buf[1];
     }
-    if (blocksize % (2 * cov::KC) == 0 && (uintptr_t)d_m % 4 == 0 && nsig >= 64) {
+    // (the one-tile-per-wave kernel keeps a whole row's sums in int32: exact up to 65536 bytes per row; longer rows take the tiled path,
+    // whose K split keeps every partial inside that bound, whatever the channel count)
+    if (blocksize > 65536 && (blocksize % (2 * cov::KC) || (uintptr_t)d_m % 4))
+        return fail(CRSDR_EINVAL, "covariance: blocksize above 65536 must be a multiple of %d (and the matrix 4-byte aligned)", 2 * cov::KC);
+    if (blocksize % (2 * cov::KC) == 0 && (uintptr_t)d_m % 4 == 0 && (nsig >= 64 || blocksize > 65536)) {
         // LDS-tiled form: 128 x 128 tiles on / above the diagonal, the K range split (in pairs of chunks) over the grid
         const int nt = (int)((nsig + cov::CT - 1) / cov::CT), ntri = nt * (nt + 1) / 2, npairs = blocksize / (2 * cov::KC);
         const int S = cov_pick_split(ntri, npairs, blocksize, device_cus());

@@ -395,8 +395,10 @@ int crsdr_plan_kernel_times(crsdr_plan *plan, int which, float *ms, int capacity
  * the reference channel, is dropped), per-channel mean removed,  Rxx = (1/L) X^H X.
  *   matrix [nrows][blocksize] int8 -- the data part of a packet (packet + crsdr_plan_matrix_offset)
  *   rxx    [(nrows-1)][(nrows-1)][2] float, row-major, rxx[a][b] = (1/L) sum_n conj(x_a[n]) x_b[n] - conj(mean_a) mean_b
- * Runs as an int8 GEMM on the matrix cores (v_mfma_i32_32x32x32_i8), exact integer sums, fp64 epilogue.
- * blocksize % 32 == 0.  mem_kind: CRSDR_MEM_HOST (copied) or CRSDR_MEM_DEVICE (both pointers on the device). */
+ * Runs as an int8 GEMM on the matrix cores (v_mfma_i32_32x32x32_i8), exact integer sums (int32 per at most 65536 bytes of a row,
+ * added in 64 bits: full-scale rows of any length are exact), fp64 epilogue.
+ * blocksize % 32 == 0; above 65536: % 512 == 0.  mem_kind: CRSDR_MEM_HOST (copied) or CRSDR_MEM_DEVICE (both pointers on the device;
+ * the matrix may sit where a packet holds it, 4-byte aligned). */
 int crsdr_covariance(float *rxx, const int8_t *matrix, int nrows, int blocksize, int mem_kind);
 
 /* Signal / noise subspaces of a Hermitian covariance, replacing noisesubspace(Rxx, K)

@@ -164,3 +164,18 @@ def test_covariance_lds_tiled_kernel_is_exact(b, nsig, B):
     b.covariance_device(out.data_ptr(), buf.data_ptr() + off, nsig + 1, B)
     got = out.cpu().numpy().view(np.complex64).reshape(nsig, nsig)
     assert np.array_equal(got, rxx)
+
+
+def test_covariance_of_long_full_scale_rows_does_not_overflow(b):
+    # rows longer than 65536 bytes: a full-scale DC row sums to more than int32 holds (2^18 bytes: 2^32), so the K range is split until
+    # every workgroup's partial is exact and the partials are added in 64 bits -- for any channel count (4 here: one padded tile)
+    nsig, B = 4, 1 << 18
+    rng = np.random.default_rng(5)
+    rows = rng.integers(-128, 128, size=(nsig + 1, B), dtype=np.int8)
+    rows[1] = -128
+    rows[2, 0::2] = 127; rows[2, 1::2] = -128
+    rxx = b.covariance(rows)
+    ref = _rxx_reference(rows)
+    assert np.abs(rxx - ref).max() <= 2e-7 * np.abs(ref).max()
+    with pytest.raises(b.CrsdrError):
+        b.covariance(np.zeros((3, 65536 + 32), dtype=np.int8))          # a long row that the K split cannot cut into 512-byte pairs
