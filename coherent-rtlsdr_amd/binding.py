@@ -133,6 +133,10 @@ def lib():
     L.crsdr_exchange_destroy.argtypes = [vp]
     L.crsdr_exchange_batch.argtypes = [vp, C.c_int, vp, vp, C.c_int, vp, C.c_size_t, vp, C.c_size_t, C.c_int, C.c_int, vp]
     L.crsdr_exchange_schedule.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_size_t, C.POINTER(XOp), C.c_int, C.POINTER(C.c_int)]
+    L.crsdr_exchange_bind_plan.argtypes = [vp, vp, C.c_int]
+    L.crsdr_exchange_submit_batch.argtypes = [vp, vp, C.c_int, C.c_int, C.c_size_t, u32p, u8p, C.c_uint32, C.c_uint32]
+    L.crsdr_exchange_fetch_rooted.argtypes = [vp, C.POINTER(C.c_int8), C.c_size_t, vp, C.c_size_t, vp, C.c_size_t, C.POINTER(C.c_int), C.POINTER(C.c_int),
+                                              C.POINTER(C.c_int)]
     L.crsdr_plan_fetch_block.argtypes = [vp, C.c_int, i32p, f32p, f32p, f32p, i8p]
     L.crsdr_plan_packet_stride.argtypes = [vp]
     L.crsdr_plan_packet_stride.restype = C.c_size_t
@@ -362,11 +366,53 @@ class Exchange:
         idbuf = C.create_string_buffer(bytes(unique_id), EXCHANGE_ID_BYTES)
         _check(lib().crsdr_exchange_create(C.byref(h), idbuf, int(nranks), int(rank), int(device)))
         self._h, self.nranks, self.rank = h, nranks, rank
+        self._plan, self._keep = None, []
 
     def batch(self, mode, send_ptr, recv_ptr, nblocks, packets_ptr, packet_stride, scalars_ptr, scalars_stride, nrows, B, stream=None):
         _check(lib().crsdr_exchange_batch(self._h, int(mode), C.c_void_p(int(send_ptr)), C.c_void_p(int(recv_ptr or 0)), int(nblocks),
                                           C.c_void_p(int(packets_ptr)), int(packet_stride), C.c_void_p(int(scalars_ptr or 0)), int(scalars_stride),
                                           int(nrows), int(B), C.c_void_p(stream or 0)))
+
+    # ---- a sharded plan and its exchange as one engine (crsdr_exchange_bind_plan / _submit_batch / _fetch_rooted) ----
+    def bind_plan(self, plan, mode=None):
+        _check(lib().crsdr_exchange_bind_plan(self._h, plan._h, int(XCHG_STAGED if mode is None else mode)))
+        self._plan, self._keep = plan, []
+
+    def submit_batch(self, rows, readcnt=None, lag_mask=None, seq=0, flags=REFNOISE_ENABLED):
+        """rows: numpy int8/uint8 [nblocks][nrows][B] on the host (page-locked or not): plan submit + exchange, all enqueued on return."""
+        keep = np.ascontiguousarray(rows)
+        if keep.ndim == 2:
+            keep = keep[None]
+        assert keep.shape[1:] == (self._plan.nrows, self._plan.B) and keep.dtype in (np.int8, np.uint8)
+        rc_arr = None if readcnt is None else np.ascontiguousarray(readcnt, dtype=np.uint32)
+        mk = None if lag_mask is None else np.ascontiguousarray(lag_mask, dtype=np.uint8)
+        self._keep.append(keep)                     # stays alive until the batch has been fetched
+        _check(lib().crsdr_exchange_submit_batch(self._h, C.c_void_p(keep.ctypes.data), MEM_HOST, keep.shape[0], 0, _p(rc_arr, C.c_uint32),
+                                                 _p(mk, C.c_uint8), int(seq), int(flags)))
+
+    def fetch_rooted(self):
+        """The oldest outstanding batch: (first, packets [count][packet_bytes] int8, scalars (list of parse_scalars dicts), own_tails dict of
+        [nblocks][per] arrays: lag, mag, frac, phasor, readcnt)."""
+        p = self._plan
+        f, c, nb = C.c_int(), C.c_int(), C.c_int()
+        if p is None:                                    # nothing bound: let the library say so
+            _check(lib().crsdr_exchange_fetch_rooted(self._h, None, 0, None, 0, None, 0, C.byref(f), C.byref(c), C.byref(nb)))
+        T, n, per = p.max_batch, p.nrows, (p.nrows - 1) // self.nranks
+        bpr = -(-T // self.nranks)
+        pk = np.zeros((bpr, p.packet_bytes), dtype=np.int8)
+        sstride = (20 * n + 15) // 16 * 16
+        tstride = (24 * per + 15) // 16 * 16
+        sc = np.zeros((bpr, sstride), dtype=np.uint8)
+        tl = np.zeros((T, tstride), dtype=np.uint8)
+        _check(lib().crsdr_exchange_fetch_rooted(self._h, _p(pk, C.c_int8), pk.strides[0], C.c_void_p(sc.ctypes.data), sstride,
+                                                 C.c_void_p(tl.ctypes.data), tstride, C.byref(f), C.byref(c), C.byref(nb)))
+        if self._keep:
+            self._keep.pop(0)
+        t = tl[:nb.value]
+        tails = dict(lag=t[:, :4 * per].copy().view(np.int32), mag=t[:, 4 * per:8 * per].copy().view(np.float32),
+                     frac=t[:, 8 * per:12 * per].copy().view(np.float32), phasor=t[:, 12 * per:20 * per].copy().view(np.complex64),
+                     readcnt=t[:, 20 * per:24 * per].copy().view(np.uint32))
+        return f.value, pk[:c.value], [parse_scalars(sc[j], n) for j in range(c.value)], tails
 
     def close(self):
         if getattr(self, "_h", None):

@@ -148,3 +148,85 @@ def test_rccl_exchange_one_rank_staged_and_in_place(tmp_path):
     for env in ({"CRSDR_XCHG_SELF": "1"}, {}):
         r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
         assert r.returncode == 0 and "EXCHANGE OK" in r.stdout, (env, r.stdout[-2000:], r.stderr[-4000:])
+
+
+def test_engine_api_one_rank_equals_the_unsharded_plan(tmp_path):
+    # crsdr_exchange_bind_plan / _submit_batch / _fetch_rooted from Python (the C++ host drives the same calls, tests/test_host_cpp.py):
+    # host rows in, this rank's assembled packets + scalars + its own rows' tails out, two batches outstanding, a ragged last batch,
+    # read counters and a masked row -- against an unsharded plan fed the same batches.  Then the state errors: a third outstanding
+    # batch, a fetch with nothing submitted, a second bind, a plan of the wrong shape.  A child per transport setting (self-loop through
+    # ncclSend / ncclRecv, and the local copy).
+    import subprocess, sys, textwrap
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = textwrap.dedent('''
+        import importlib, sys, numpy as np
+        sys.path.insert(0, %r)
+        pkg = importlib.import_module("coherent-rtlsdr_amd")
+        b, synth = pkg.binding, pkg.synth
+        nsig, L, T = 24, 8192, 5
+        nrows, B = nsig + 1, 2 * L
+        params = synth.RowParams(nsig, L, 43, dmax=500)
+        blocks = np.stack([synth.make_block(nsig, L, 43, t, params=params)[0] for t in range(3 * T)])
+        rc = (100 + 5 * np.arange(3 * T)[:, None] + np.arange(nrows)[None, :]).astype(np.uint32)
+        mask = np.ones(nrows, dtype=np.uint8); mask[4] = 0                     # row 4 never asks for a lag: it keeps its carried one
+        sizes = [T, T, 3]                                                       # the last batch is short
+        ref = b.Plan(nrows, B, b.MODE_DIGITAL, max_batch=T)
+        exp, at = [], 0
+        for nb in sizes:
+            ref.submit(blocks[at:at + nb], readcnt=rc[at:at + nb], lag_mask=mask, seq=at)
+            exp.append([ref.fetch(block=t) for t in range(nb)])
+            at += nb
+        x = b.Exchange(b.exchange_unique_id(), 1, 0, 0)
+        try:
+            x.fetch_rooted()
+            raise SystemExit("fetch without a bound plan did not fail")
+        except b.CrsdrError:
+            pass
+        plan = b.Plan(nrows, B, b.MODE_DIGITAL, max_batch=T)
+        wrong = b.Plan(nrows, B, b.MODE_DIGITAL, row_begin=1, row_count=nsig // 2, max_batch=T)
+        try:
+            x.bind_plan(wrong)
+            raise SystemExit("a plan that does not own the rank's slab was accepted")
+        except b.CrsdrError:
+            pass
+        x.bind_plan(plan)
+        try:
+            x.bind_plan(plan)
+            raise SystemExit("second bind accepted")
+        except b.CrsdrError:
+            pass
+        try:
+            x.fetch_rooted()
+            raise SystemExit("fetch with nothing submitted did not fail")
+        except b.CrsdrError:
+            pass
+        got = []
+        x.submit_batch(blocks[0:T], readcnt=rc[0:T], lag_mask=mask, seq=0)
+        x.submit_batch(blocks[T:2 * T], readcnt=rc[T:2 * T], lag_mask=mask, seq=T)      # two outstanding
+        try:
+            x.submit_batch(blocks[2 * T:2 * T + 3], seq=2 * T)
+            raise SystemExit("a third outstanding batch was accepted")
+        except b.CrsdrError:
+            pass
+        got.append(x.fetch_rooted())
+        x.submit_batch(blocks[2 * T:2 * T + 3], readcnt=rc[2 * T:2 * T + 3], lag_mask=mask, seq=2 * T)
+        got.append(x.fetch_rooted())
+        got.append(x.fetch_rooted())
+        at = 0
+        for k, nb in enumerate(sizes):
+            first, pk, sc, tails = got[k]
+            assert first == 0 and len(pk) == nb and len(sc) == nb, (k, first, len(pk))
+            for t in range(nb):
+                e = exp[k][t]
+                assert np.array_equal(pk[t], e["packet"]), (k, t)
+                for key in ("lag", "mag", "frac", "phasor"):
+                    assert np.array_equal(sc[t][key].view(np.uint8), e[key].view(np.uint8)), (k, t, key)
+                    assert np.array_equal(tails[key][t].view(np.uint8), e[key][1:].view(np.uint8)), (k, t, key)      # one rank owns every signal row
+                assert np.array_equal(tails["readcnt"][t], rc[at + t][1:]), (k, t)
+            at += nb
+        x.close(); plan.close(); wrong.close(); ref.close()
+        print("ENGINE OK")
+    ''') % root
+    for env in ({"CRSDR_XCHG_SELF": "1"}, {}):
+        r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0 and "ENGINE OK" in r.stdout, (env, r.stdout[-2000:], r.stderr[-4000:])
