@@ -45,7 +45,7 @@ def parse():
                     "0 = 64, the plan's maximum (measured on one GPU: 16.5 k blocks/s at 8, 17.1 k at 16, 17.6 k at 64)")
     ap.add_argument("--mode", choices=["digital", "faithful"], default="digital")
     ap.add_argument("--cfg5", action="store_true", help="BASELINE config 5 instead: 1 + 21 rows x 2^20 samples (long-block path)")
-    ap.add_argument("--frac-apply", action="store_true", help="with --cfg5: fractional-delay correction on (crsdr_plan_set_frac_apply, D = this block's estimate)")
+    ap.add_argument("--frac-apply", action="store_true", help="fractional-delay correction on (crsdr_plan_set_frac_apply, D = this block's estimate): an extra, never the default workload")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the locked-mode / large-working-set extras")
     ap.add_argument("--skip-pcie", action="store_true", help="skip the host-buffer (PCIe-inclusive) extra: its submits carry 16 blocks, "
@@ -135,7 +135,7 @@ def main():
     assert stream.cuda_stream != 0
     torch.cuda.synchronize()                            # the input blocks above were filled on the null stream
     plan.set_stream(stream.cuda_stream)
-    if args.cfg5 and args.frac_apply:
+    if args.frac_apply:
         plan.set_frac_apply(True, 1.0, None)
     # NSETS ring-buffered output sets (the exchange of batch i runs under the compute of batch i+1); the matrix
     # of every packet is 16-byte aligned.  One GPU: T packets per set.  Several GPUs: per set one slot buffer
@@ -363,7 +363,7 @@ def main():
                                    f"(FFT xcorr every block), {args.mode} mode, inputs resident in HBM, "
                                    f"{nbuf} rotating input blocks, {T} blocks per submit",
                        "rows": nrows, "L": L, "fft_len": B, "mode": args.mode, "batch": T,
-                       "forced_exchange_path": force_x,
+                       "forced_exchange_path": force_x, "frac_apply": bool(args.frac_apply),
                        "parallelism": f"rows sharded x{world}, ref replicated, rotating-root gather of int8 rows + 24 B/row {{lag, mag, frac, phasor, readcnt}}: one RCCL all-to-all per {T}-block batch + local assembly, overlapped with the next batch" if world > 1 else "single GPU"},
             "roofline": {"bound": "hbm", "kernel": "k_xcorr_lag", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": _committed_traffic("k_xcorr_lag", tb)[0],
