@@ -427,8 +427,19 @@ static hipError_t launch_long_inv_cols(hipStream_t s, int nrows_launch, const fl
 }
 
 template <int LOG2N>
-static hipError_t launch_frac_apply(hipStream_t s, int row_count, int nblocks, const FracArgs &fa, const float2 *tw)
+static hipError_t launch_frac_apply(hipStream_t s, int row_count, int nblocks, const FracArgs &fa, const float2 *tw, const float2 *twA, const float2 *twB,
+                                    const uint32_t *k2tab)
 {
+    if constexpr (LOG2N == 14) {
+        if (k2tab && twA && twB) {             // the pass on K1's 32 x 32 x 16 network (xcorr14p.hpp)
+            x14p::FracRowArgs ra{fa.rows, fa.block_stride, fa.packet, fa.packet_stride, fa.slab, fa.slab_stride, fa.nrows, fa.row_begin, fa.xor80, fa.lag, fa.frac,
+                                 fa.frac_override, fa.gain, fa.phasor, k2tab, tw};
+            hipError_t e = hipFuncSetAttribute((const void *)x14p::k_frac_apply14, hipFuncAttributeMaxDynamicSharedMemorySize, x14::LDS_BYTES);
+            if (e != hipSuccess) return e;
+            hipLaunchKernelGGL(x14p::k_frac_apply14, dim3(row_count, nblocks), dim3(x14::THREADS), x14::LDS_BYTES, s, ra, twA, twB);
+            return hipGetLastError();
+        }
+    }
     auto kern = k_frac_apply<LOG2N>;
     constexpr size_t lds = sizeof(float2) * ((size_t)1 << LOG2N) + 256;
     hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -812,6 +823,7 @@ struct crsdr_plan {
     float frac_gain = 1.0f;
     float *d_frac_override = nullptr;   // [nrows]
     uint32_t *d_k2tab = nullptr;        // [8192] frequency index k2 of every junction register pair of the row transforms
+    bool frac_generic = false;          // CRSDR_FRAC_GENERIC=1: B = 16384 takes the generic fractional-delay kernel too (A/B, tests)
     float2 *d_Z = nullptr;              // second work area (set_frac_apply): the correlation pass's stage B writes here, so that the apply pass finds stage A's output still in d_Y
     float4 *d_rowspec = nullptr;        // [row_count][8192] the rows' responses G(k2) in the junction's order (k_ramp_rowspec); allocated by set_frac_apply
     // pinned staging ring for the small per-batch host arrays
@@ -868,12 +880,17 @@ static hipError_t launch_long_rows_ref1(hipStream_t s, float2 *Y, const float2 *
 static int make_k2tab(crsdr_plan *p)
 {
     const size_t N2 = lb::N2;
-    HIP_TRY(hipMemset(p->d_Yref, 0, sizeof(float2) * N2));
+    float2 *line = p->d_Yref;              // long blocks have a line of their own; a 16384-point plan borrows one for this call
+    if (!line) HIP_TRY(hipMalloc((void **)&line, sizeof(float2) * N2));
+    const auto give_back = [&]() { if (line != p->d_Yref) (void)hipFree(line); };
+    hipError_t e0 = hipMemset(line, 0, sizeof(float2) * N2);
     const float2 one = make_float2(1.0f, 0.0f);
-    HIP_TRY(hipMemcpy(p->d_Yref + 1, &one, sizeof(one), hipMemcpyHostToDevice));
-    HIP_TRY(hipDeviceSynchronize());       // the plan's streams are non-blocking: no implicit order with the null stream
-    HIP_TRY(launch_long_rows_ref1(p->own_stream, p->d_Yref, p->d_twA, p->d_twB, p->d_refspec[0]));
-    HIP_TRY(hipStreamSynchronize(p->own_stream));
+    if (e0 == hipSuccess) e0 = hipMemcpy(line + 1, &one, sizeof(one), hipMemcpyHostToDevice);
+    if (e0 == hipSuccess) e0 = hipDeviceSynchronize();       // the plan's streams are non-blocking: no implicit order with the null stream
+    if (e0 == hipSuccess) e0 = launch_long_rows_ref1(p->own_stream, line, p->d_twA, p->d_twB, p->d_refspec[0]);
+    if (e0 == hipSuccess) e0 = hipStreamSynchronize(p->own_stream);
+    give_back();
+    HIP_TRY(e0);
     std::vector<float2> h(N2);
     HIP_TRY(hipMemcpy(h.data(), p->d_refspec[0], sizeof(float2) * N2, hipMemcpyDeviceToHost));
     std::vector<uint32_t> tab(N2 / 2);
@@ -952,6 +969,7 @@ static int plan_alloc(crsdr_plan *p)
     HIP_TRY(hipMemset(p->d_refflag, 0, sizeof(unsigned int) * T));
     { const char *e = getenv("CRSDR_K1_FOLD"); if (e) p->fold = atoi(e) != 0; }
     { const char *e = getenv("CRSDR_K2_FUSED"); if (e) p->fused_k2 = atoi(e) != 0; }
+    { const char *e = getenv("CRSDR_FRAC_GENERIC"); if (e) p->frac_generic = atoi(e) != 0; }
     {
         const size_t n8 = (n + 1) / 2 * 2;                   // keeps the float2 arrays 8-byte aligned
         p->state_bytes = n8 * (3 * 4 + 2 * 8);
@@ -965,7 +983,7 @@ static int plan_alloc(crsdr_plan *p)
     }
     HIP_TRY(hipHostMalloc((void **)&p->h_readcnt, sizeof(uint32_t) * n * T * kStageSlots, hipHostMallocDefault));
     HIP_TRY(hipHostMalloc((void **)&p->h_mask, n * kStageSlots, hipHostMallocDefault));
-    if (p->longblock) { int rc = make_k2tab(p); if (rc) return rc; }
+    if (p->longblock || p->log2n == 14) { int rc = make_k2tab(p); if (rc) return rc; }      // (short blocks: the fractional-delay pass on K1's network)
     HIP_TRY(hipMalloc((void **)&p->d_frac_override, sizeof(float) * (size_t)p->nrows));
     HIP_TRY(hipMemset(p->d_frac_override, 0, sizeof(float) * (size_t)p->nrows));
     return plan_init_state(p);
@@ -1472,7 +1490,7 @@ extern "C" int crsdr_plan_submit_batch(crsdr_plan *p, const void *rows, int mem_
             // fractional-delay correction of LDS-resident blocks: the owned rows once more, through the frequency domain
             FracArgs fa{d_in, d_stride, p->d_packet, p->packet_stride, p->d_slab, p->slab_stride, p->nrows, p->row_begin, xor80, o_lag, o_frac,
                         p->frac_override_on ? p->d_frac_override : nullptr, p->frac_gain, p->d_phasor};
-            HIP_TRY(CRSDR_DISPATCH_LOG2(p->log2n, (launch_frac_apply<LG>(S, p->row_count, nblocks, fa, p->d_tw))));
+            HIP_TRY(CRSDR_DISPATCH_LOG2(p->log2n, (launch_frac_apply<LG>(S, p->row_count, nblocks, fa, p->d_tw, p->d_twA, p->d_twB, p->frac_generic ? nullptr : p->d_k2tab))));
         }
         if (pe) HIP_TRY(hipEventRecord(pe[1], S));
         { int rc_ = pack_tails(p, S, nblocks, o_lag, o_mag, o_frac, d_readcnt, seq); if (rc_) return rc_; }
@@ -1541,7 +1559,7 @@ extern "C" int crsdr_plan_submit_batch(crsdr_plan *p, const void *rows, int mem_
         } else if (p->frac_apply && !p->longblock && aa.digital) {       // LDS-resident blocks on the three-kernel path: as behind the fused kernel
             FracArgs fa{d_in, d_stride, p->d_packet, p->packet_stride, p->d_slab, p->slab_stride, p->nrows, p->row_begin, xor80, o_lag, o_frac,
                         p->frac_override_on ? p->d_frac_override : nullptr, p->frac_gain, p->d_phasor};
-            HIP_TRY(CRSDR_DISPATCH_LOG2(p->log2n, (launch_frac_apply<LG>(S, p->row_count, nblocks, fa, p->d_tw))));
+            HIP_TRY(CRSDR_DISPATCH_LOG2(p->log2n, (launch_frac_apply<LG>(S, p->row_count, nblocks, fa, p->d_tw, p->d_twA, p->d_twB, p->frac_generic ? nullptr : p->d_k2tab))));
         }
         if (pe) HIP_TRY(hipEventRecord(pe[1], S));
     }

@@ -595,6 +595,129 @@ __global__ __launch_bounds__(THREADS, 2) void k_rows14_cf32p(c2 *__restrict__ Y,
 }
 
 
+// ---- fractional-delay correction of a 16384-point block on K1's network (crsdr_plan_set_frac_apply at the reference's block size) ----
+// The generic form (kernels.hpp k_frac_apply<LOG2N>: the radix-16 LDS network of fft_lds.hpp) costs 50 us per row and CU at this size;
+// this is the same pass on the 32 x 32 x 16 network: K1's int8 first pass and its P1, the junction as in the long blocks' stage B''
+// (k_rows14_cf32p<false, true> with N1 = 1: DFT16, every bin times H[k] = p / B . exp(+2 pi i k_s (lag + D) / B), inverse DFT16; the
+// frequency of every junction register from the plan's k2tab, integer part of the exponent from the plan's forward table, fractional
+// part by polynomial), P1', and a last pass whose first L outputs are quantised like cdsp::convto8bit and laid out in natural order
+// in the (by then free) LDS image, so that the row leaves as 16-byte stores.  The 1/127 of convtofloat and the x 127 of convto8bit
+// are a common factor of the linear chain and cancel: the transforms run on integer-valued floats, as in K1.
+struct FracRowArgs {
+    const int8_t *rows;
+    size_t block_stride;
+    int8_t *packet;
+    size_t packet_stride;
+    int8_t *slab;              // slab output (sharded plans) or nullptr
+    size_t slab_stride;
+    int nrows, row_begin;
+    uint32_t xor80;
+    const int32_t *lag;        // [T][nrows] this batch's lags
+    const float *frac;         // [T][nrows] this batch's parabolic estimates
+    const float *frac_override; // [nrows] or nullptr: D = gain * frac
+    float gain;
+    const float2 *phasor;      // [T][nrows] get_phasecorrect() after each block
+    const uint32_t *k2tab;     // [8192] frequency index of every junction register pair
+    const float2 *tw;          // [16384] W_N^m = exp(-2 pi i m / N)
+};
+
+// grid (owned rows, blocks)
+__global__ __launch_bounds__(THREADS, 2) void k_frac_apply14(FracRowArgs a, const float2 *__restrict__ twA_, const float2 *__restrict__ twB_)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    c2 *A = reinterpret_cast<c2 *>(smem);
+    float4 *A4 = reinterpret_cast<float4 *>(smem);
+    const c2 *twA = reinterpret_cast<const c2 *>(twA_), *twB = reinterpret_cast<const c2 *>(twB_);
+    const int tid = threadIdx.x, t = blockIdx.y, row = a.row_begin + (int)blockIdx.x;
+    const size_t o = (size_t)t * a.nrows + row;
+    c2 wA[32];
+    pass0_forward<false>(A, a.rows + (size_t)t * a.block_stride + (size_t)row * N, twA, a.xor80, tid, wA);
+    c2 wB[32];
+    tw_load(wB, twB, TWB_STRIDE, tid & 15);
+    __syncthreads();
+    pass1_forward(A, wB, tid);
+    wave_lds_sync();
+    {
+        const uint32_t lagu = (uint32_t)a.lag[o];
+        const float invN = 1.0f / (float)N;
+        const float D = a.frac_override ? a.frac_override[row] : a.gain * a.frac[o];
+        const float2 pr = a.phasor[o];
+        const c2 pb = mk(pr.x * invN, pr.y * invN);
+        const float dstep = D * invN;
+#pragma unroll 1
+        for (int h = 0; h < 2; ++h) {
+            const int g = ((tid >> 6) << 7) + 64 * h + (tid & 63), base = j_base(g), key = g & 7;
+            c2 rr[16];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const uint32_t kk = a.k2tab[j * 1024 + g];
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const uint32_t k = e ? (kk >> 16) : (kk & 0xffffu);
+                    const int ks = k < (uint32_t)L ? (int)k : (int)k - N;
+                    const float2 w = a.tw[(k * lagu) & (uint32_t)(N - 1)];       // its conjugate is the integer part exp(+2 pi i (k lag mod N) / N)
+                    rr[2 * j + e] = cmul(cmulc(pb, mk(w.x, w.y)), cis2pi((float)ks * dstep));
+                }
+            }
+            c2 u[16];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float4 q = A4[base + (j ^ key)];
+                u[2 * j] = mk(q.x, q.y);
+                u[2 * j + 1] = mk(q.z, q.w);
+            }
+            dft16p<-1>(u);
+#if CRSDR_K1_FUSED_TW
+            dft16_inv_mul(u, rr);
+#else
+#pragma unroll
+            for (int j = 0; j < 16; ++j) u[j] = cmul(u[j], rr[j]);
+            dft16p<+1>(u);
+#endif
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                A4[base + (j ^ key)] = make_float4(u[2 * j].x, u[2 * j].y, u[2 * j + 1].x, u[2 * j + 1].y);
+        }
+    }
+    wave_lds_sync();
+    pass1_inverse(A, wB, tid);
+    __syncthreads();
+    uint32_t out16[16];
+    {
+        c2 v[32];
+        const int base = p0_base(tid);
+#pragma unroll
+        for (int k = 0; k < 32; ++k) v[k] = A[base + k * 528];
+        tw_dft32_inv(v, wA);
+        // cpacketize::write(complex<float>*) -> cdsp::convto8bit (src/cpacketizer.cc:158-172, src/cdsp.cc:51-54) on the first L samples:
+        // outputs i * 512 + tid, i < 16
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const c2 x = v[xpos(i)];
+            const int qr = (int)rintf(fminf(fmaxf(x.x, -128.0f), 127.0f)), qi = (int)rintf(fminf(fmaxf(x.y, -128.0f), 127.0f));
+            out16[i] = ((uint32_t)qr & 0xffu) | (((uint32_t)qi & 0xffu) << 8);
+        }
+    }
+    __syncthreads();                                             // every thread has taken its part of the image: it becomes the output row
+    uint16_t *ob = reinterpret_cast<uint16_t *>(smem);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) ob[i * 512 + tid] = (uint16_t)out16[i];
+    __syncthreads();
+    int8_t *orow = a.slab ? a.slab + (size_t)t * a.slab_stride + (size_t)(row - a.row_begin) * N
+                          : a.packet + (size_t)t * a.packet_stride + 16 + 4 * (size_t)a.nrows + (size_t)row * N;
+    if (((uintptr_t)orow & 15) == 0) {
+        const uint4 *s4 = reinterpret_cast<const uint4 *>(smem);
+        uint4 *d4 = reinterpret_cast<uint4 *>(orow);
+        d4[tid] = s4[tid];
+        d4[tid + THREADS] = s4[tid + THREADS];
+    } else {                                                     // a bound packet whose matrix is only 4-byte aligned
+        const uint32_t *s1 = reinterpret_cast<const uint32_t *>(smem);
+        uint32_t *d1 = reinterpret_cast<uint32_t *>(orow);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) d1[tid + q * THREADS] = s1[tid + q * THREADS];
+    }
+}
+
 // grid: fold * blocks + owned rows * blocks workgroups, one-dimensional.  fold = 1: the first `blocks` workgroups are the blocks'
 // reference items -- every one of them has a lower index than any row workgroup, so in-order dispatch has them all resident (or done)
 // before a row can wait for one, and only the first rows of a launch ever do (with the reference item NEXT to its block's rows,

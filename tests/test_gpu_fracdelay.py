@@ -7,6 +7,7 @@ same ramp, plus a known answer: a band-limited row delayed by a non-integer numb
 Bars: int8 matrix equal to the oracle / model except +-1 LSB at rounding boundaries (the two sides run different fp32 FFT
 factorisations; v_sin / v_cos against libm), lags and phasors as everywhere else."""
 import importlib
+import os
 
 import numpy as np
 import pytest
@@ -264,3 +265,56 @@ def test_frac_apply_without_second_work_area_is_bit_identical(b, synth):
         for key in ("lag", "mag", "frac", "phasor", "packet"):
             assert np.array_equal(outs[1][t][key].view(np.uint8), outs[2][t][key].view(np.uint8)), (t, key)
         assert np.array_equal(outs[1][t]["lag"][1:], params.d)
+
+
+def test_frac_apply_at_16384_both_kernels_and_bound_packets(tmp_path):
+    # B = 16384 runs the correction on K1's 32 x 32 x 16 network (k_frac_apply14: junction with the response, natural-order bytes through
+    # the LDS image); CRSDR_FRAC_GENERIC=1 keeps the generic radix-16 kernel every other size uses.  Same definition, different
+    # factorisation: the two agree except +-1 LSB on a few entries per thousand -- on the plan's own packets, on a caller's packet whose
+    # matrix is only 4-byte aligned (dword stores) and through the three-kernel phase path.  Children: the switch is read per plan
+    # from the environment of the process.
+    import subprocess, sys, textwrap
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = textwrap.dedent('''
+        import importlib, sys, numpy as np, torch
+        sys.path.insert(0, %r)
+        pkg = importlib.import_module("coherent-rtlsdr_amd")
+        b, synth = pkg.binding, pkg.synth
+        nsig, L, T = 9, 8192, 3
+        nrows, B = nsig + 1, 2 * L
+        params = synth.RowParams(nsig, L, 733, dmax=900)
+        D = np.linspace(-0.5, 0.5, nrows).astype(np.float32)
+        blocks = np.stack([synth.make_block(nsig, L, 733, t, params=params)[0] for t in range(T)])
+        res = {}
+        plan = b.Plan(nrows, B, b.MODE_DIGITAL, max_batch=T)
+        plan.set_frac_apply(True, 1.0, D)
+        plan.submit(blocks, seq=0)
+        res["own"] = np.stack([plan.fetch(block=t)["packet"] for t in range(T)])
+        dev = torch.device("cuda", 0)
+        pstride = (plan.packet_bytes + 255) // 256 * 256
+        buf = torch.zeros(T * pstride + 64, dtype=torch.uint8, device=dev)
+        off = (-buf.data_ptr()) %% 256                                  # packets 256-byte aligned: the matrix at +16 + 4 N is 4-byte aligned only
+        assert (buf.data_ptr() + off + plan.matrix_offset) %% 16 != 0
+        plan2 = b.Plan(nrows, B, b.MODE_DIGITAL, max_batch=T)
+        plan2.set_frac_apply(True, 1.0, D)
+        plan2.bind_packet(buf.data_ptr() + off, pstride)
+        plan2.submit(blocks, seq=0)
+        plan2.sync()
+        res["bound"] = np.stack([buf[off + t * pstride: off + t * pstride + plan.packet_bytes].cpu().numpy().view(np.int8) for t in range(T)])
+        np.savez(sys.argv[1], **res)
+    ''') % root
+    outs = {}
+    for name, env in (("fast", {}), ("generic", {"CRSDR_FRAC_GENERIC": "1"}), ("fast_three", {"CRSDR_K2_FUSED": "0"})):
+        out = tmp_path / f"{name}.npz"
+        r = subprocess.run([sys.executable, "-c", code, str(out)], env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout + r.stderr
+        outs[name] = np.load(out)
+    moff = 16 + 4 * 10
+    for name in ("fast", "generic", "fast_three"):
+        # the 4-byte aligned bound packet holds what the plan's own packet holds, bit for bit
+        assert np.array_equal(outs[name]["own"], outs[name]["bound"]), name
+    assert np.array_equal(outs["fast"]["own"], outs["fast_three"]["own"])
+    a, g = outs["fast"]["own"][:, moff:].astype(np.int32), outs["generic"]["own"][:, moff:].astype(np.int32)
+    diff = np.abs(a - g)
+    assert diff.max() <= 1 and np.count_nonzero(diff) <= 2e-3 * diff.size, (diff.max(), np.count_nonzero(diff), diff.size)
+    assert np.array_equal(outs["fast"]["own"][:, :moff], outs["generic"]["own"][:, :moff])          # header + read counters
