@@ -434,9 +434,10 @@ static hipError_t launch_frac_apply(hipStream_t s, int row_count, int nblocks, c
         if (k2tab && twA && twB) {             // the pass on K1's 32 x 32 x 16 network (xcorr14p.hpp)
             x14p::FracRowArgs ra{fa.rows, fa.block_stride, fa.packet, fa.packet_stride, fa.slab, fa.slab_stride, fa.nrows, fa.row_begin, fa.xor80, fa.lag, fa.frac,
                                  fa.frac_override, fa.gain, fa.phasor, k2tab, tw};
-            hipError_t e = hipFuncSetAttribute((const void *)x14p::k_frac_apply14, hipFuncAttributeMaxDynamicSharedMemorySize, x14::LDS_BYTES);
+            constexpr int lds14 = x14::LDS_BYTES + 2048;          // the image + the row's two response tables
+            hipError_t e = hipFuncSetAttribute((const void *)x14p::k_frac_apply14, hipFuncAttributeMaxDynamicSharedMemorySize, lds14);
             if (e != hipSuccess) return e;
-            hipLaunchKernelGGL(x14p::k_frac_apply14, dim3(row_count, nblocks), dim3(x14::THREADS), x14::LDS_BYTES, s, ra, twA, twB);
+            hipLaunchKernelGGL(x14p::k_frac_apply14, dim3(row_count, nblocks), dim3(x14::THREADS), lds14, s, ra, twA, twB);
             return hipGetLastError();
         }
     }

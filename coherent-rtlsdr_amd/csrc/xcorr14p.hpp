@@ -598,9 +598,8 @@ __global__ __launch_bounds__(THREADS, 2) void k_rows14_cf32p(c2 *__restrict__ Y,
 // ---- fractional-delay correction of a 16384-point block on K1's network (crsdr_plan_set_frac_apply at the reference's block size) ----
 // The generic form (kernels.hpp k_frac_apply<LOG2N>: the radix-16 LDS network of fft_lds.hpp) costs 50 us per row and CU at this size;
 // this is the same pass on the 32 x 32 x 16 network: K1's int8 first pass and its P1, the junction as in the long blocks' stage B''
-// (k_rows14_cf32p<false, true> with N1 = 1: DFT16, every bin times H[k] = p / B . exp(+2 pi i k_s (lag + D) / B), inverse DFT16; the
-// frequency of every junction register from the plan's k2tab, integer part of the exponent from the plan's forward table, fractional
-// part by polynomial), P1', and a last pass whose first L outputs are quantised like cdsp::convto8bit and laid out in natural order
+// (DFT16, every bin times H[k] = p / B . exp(+2 pi i k_s (lag + D) / B), inverse DFT16; the frequency of every junction register from
+// the plan's k2tab, the response from two 128-entry tables of the row), P1', and a last pass whose first L outputs are quantised like cdsp::convto8bit and laid out in natural order
 // in the (by then free) LDS image, so that the row leaves as 16-byte stores.  The 1/127 of convtofloat and the x 127 of convto8bit
 // are a common factor of the linear chain and cancel: the transforms run on integer-valued floats, as in K1.
 struct FracRowArgs {
@@ -630,6 +629,26 @@ __global__ __launch_bounds__(THREADS, 2) void k_frac_apply14(FracRowArgs a, cons
     const c2 *twA = reinterpret_cast<const c2 *>(twA_), *twB = reinterpret_cast<const c2 *>(twB_);
     const int tid = threadIdx.x, t = blockIdx.y, row = a.row_begin + (int)blockIdx.x;
     const size_t o = (size_t)t * a.nrows + row;
+    // The response of the row, H[k] = p / N . exp(+2 pi i k_s (lag + D) / N), as a product of two 128-entry tables over k = 128 k_hi + k_lo,
+    // built once per row behind the image (formed per bin it was 45 vector instructions + a gather, 1.7 x K1's whole row):
+    //   R_hi[h] = conj(W^((128 h lag) mod N)) . cis(128 h D / N) . (h >= 64 ? cis(-D) : 1)      (k >= L: k_s = k - N)
+    //   R_lo[l] = p / N . conj(W^((l lag) mod N)) . cis(l D / N)
+    // integer parts reduced mod N in integers and read from the plan's forward table, fractional parts by polynomial.
+    c2 *Rhi = reinterpret_cast<c2 *>(smem + (size_t)LDS_ELEMS * 8 + 512), *Rlo = Rhi + 128;
+    if (tid < 256) {
+        const uint32_t lagu = (uint32_t)a.lag[o];
+        const float invN = 1.0f / (float)N;
+        const float D = a.frac_override ? a.frac_override[row] : a.gain * a.frac[o];
+        const float dstep = D * invN;
+        const uint32_t idx = (uint32_t)tid & 127u, k = tid < 128 ? idx << 7 : idx;
+        const float2 w = a.tw[(k * lagu) & (uint32_t)(N - 1)];
+        c2 r = cmulc(cis2pi((float)k * dstep - ((tid < 128 && idx >= 64u) ? D : 0.0f)), mk(w.x, w.y));
+        if (tid >= 128) {
+            const float2 pr = a.phasor[o];
+            r = cmul(r, mk(pr.x * invN, pr.y * invN));
+        }
+        (tid < 128 ? Rhi : Rlo)[idx] = r;
+    }
     c2 wA[32];
     pass0_forward<false>(A, a.rows + (size_t)t * a.block_stride + (size_t)row * N, twA, a.xor80, tid, wA);
     c2 wB[32];
@@ -638,12 +657,6 @@ __global__ __launch_bounds__(THREADS, 2) void k_frac_apply14(FracRowArgs a, cons
     pass1_forward(A, wB, tid);
     wave_lds_sync();
     {
-        const uint32_t lagu = (uint32_t)a.lag[o];
-        const float invN = 1.0f / (float)N;
-        const float D = a.frac_override ? a.frac_override[row] : a.gain * a.frac[o];
-        const float2 pr = a.phasor[o];
-        const c2 pb = mk(pr.x * invN, pr.y * invN);
-        const float dstep = D * invN;
 #pragma unroll 1
         for (int h = 0; h < 2; ++h) {
             const int g = ((tid >> 6) << 7) + 64 * h + (tid & 63), base = j_base(g), key = g & 7;
@@ -654,9 +667,7 @@ __global__ __launch_bounds__(THREADS, 2) void k_frac_apply14(FracRowArgs a, cons
 #pragma unroll
                 for (int e = 0; e < 2; ++e) {
                     const uint32_t k = e ? (kk >> 16) : (kk & 0xffffu);
-                    const int ks = k < (uint32_t)L ? (int)k : (int)k - N;
-                    const float2 w = a.tw[(k * lagu) & (uint32_t)(N - 1)];       // its conjugate is the integer part exp(+2 pi i (k lag mod N) / N)
-                    rr[2 * j + e] = cmul(cmulc(pb, mk(w.x, w.y)), cis2pi((float)ks * dstep));
+                    rr[2 * j + e] = cmul(Rhi[k >> 7], Rlo[k & 127u]);
                 }
             }
             c2 u[16];
