@@ -77,7 +77,7 @@ __device__ __forceinline__ void col_fft(float2 *T, const float2 *__restrict__ tw
         constexpr int LOG2C = LOG2TILE - LOG2N1, C = 1 << LOG2C;
         constexpr int LR = G::log2r(P), R = 1 << LR, LM = G::log2m(P), M = 1 << LM;
         constexpr int NG = TILE / R;
-#pragma unroll(SUNK ? NG / THREADS : 1)
+#pragma unroll SUNK ? NG / THREADS : 1
         for (int it = 0; it < NG / THREADS; ++it) {
             const int g = tid + it * THREADS;
             const int c = g & (C - 1), gi = g >> LOG2C;
