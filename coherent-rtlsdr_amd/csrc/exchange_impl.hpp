@@ -214,7 +214,7 @@ extern "C" int crsdr_assemble_slots(void *device_packets, size_t packet_stride, 
         return fail(CRSDR_EINVAL, "assemble_slots: 4-byte alignment of every pointer / stride, slots >= rows (+ tail), strides >= one packet / scalars block");
     { int rc_ = require_device(); if (rc_) return rc_; }
     return launch_assemble((hipStream_t)hip_stream, (int8_t *)device_packets, packet_stride, (int8_t *)device_scalars, scalars_stride, nrows, g.per, blocksize,
-                           (const int8_t *)device_recv, nsrc, nblocks, slot_stride, tail_offset, tail_offset != 0 && device_scalars != nullptr, 0, -1,
+                           (const int8_t *)device_recv, nsrc, nblocks, slot_stride, tail_offset, tail_offset != 0 /* read counters reach the headers with or without a scalars block */, 0, -1,
                            device_self ? self_rank : -1, (const int8_t *)device_self, 0);
 }
 
@@ -346,7 +346,7 @@ extern "C" int crsdr_exchange_batch(crsdr_exchange *x, int mode, const void *dev
     }
     if (myc < 1) return CRSDR_OK;
     const int8_t *self_slots = (const int8_t *)device_send + (size_t)myf * g.slot;
-    const bool tails = device_scalars != nullptr;
+    const bool tails = true;      // exchange slots always carry tails: their read counters go into the packet headers even where no scalars block is wanted
     if (mode == CRSDR_XCHG_STAGED)
         return launch_assemble(s, (int8_t *)device_packets, packet_stride, (int8_t *)device_scalars, scalars_stride, nrows, g.per, blocksize, (const int8_t *)device_recv,
                                x->nranks, myc, g.slot, g.rows_bytes, tails, 0, -1, x->selfloop ? -1 : x->rank, x->selfloop ? nullptr : self_slots, 0);
@@ -438,7 +438,7 @@ extern "C" int crsdr_exchange_fetch_rooted(crsdr_exchange *x, int8_t *packets, s
     const int k = (int)(x->head & 1), c = x->out[k].count;
     if (packets && c > 1 && host_packet_stride < p->packet_bytes) return fail(CRSDR_EINVAL, "exchange_fetch_rooted: host_packet_stride smaller than a packet");
     if (scalars && c > 1 && host_scalars_stride < 20 * (size_t)p->nrows) return fail(CRSDR_EINVAL, "exchange_fetch_rooted: host_scalars_stride smaller than 20 * nrows");
-    if (own_tails && x->out[k].nblocks > 1 && host_tails_stride < x->geo.tail_bytes) return fail(CRSDR_EINVAL, "exchange_fetch_rooted: host_tails_stride smaller than 20 * rows per rank");
+    if (own_tails && x->out[k].nblocks > 1 && host_tails_stride < x->geo.tail_bytes) return fail(CRSDR_EINVAL, "exchange_fetch_rooted: host_tails_stride smaller than 24 * rows per rank");
     HIP_TRY(hipSetDevice(x->device));
     HIP_TRY(hipStreamWaitEvent(x->cs, x->ev_done[k], 0));
     const int8_t *pk = x->d_packets[k] + x->pk_off[k];

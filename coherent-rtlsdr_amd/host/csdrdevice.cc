@@ -89,7 +89,10 @@ int8_t *csyntheticsdr::read()
 
 void csyntheticsdr::consume()
 {
-    if (ring) { std::lock_guard<std::mutex> lock(mtx); if (held) { held = false; ring->consume(); } }
+    if (ring) {
+        { std::lock_guard<std::mutex> lock(mtx); if (held) { held = false; ring->consume(); } }
+        cv_space.notify_all();
+    }
 }
 
 void csyntheticsdr::asynch_threadf(csyntheticsdr *d)
@@ -106,6 +109,8 @@ void csyntheticsdr::asynch_threadf(csyntheticsdr *d)
         }
         {
             std::unique_lock<std::mutex> lock(d->mtx);
+            if (d->lossless) d->cv_space.wait(lock, [d] { return d->ring->backlog() < d->ring->capacity() || d->do_exit.load(); });
+            if (d->do_exit) break;
             if (d->ring->backlog() >= d->ring->capacity()) {  // consumer too slow: a block is lost (README.md:42)
                 d->overruns++;
                 if (d->held) {
@@ -144,6 +149,7 @@ bool csyntheticsdr::start_replay(const char *path, int pace_us_, int max_blocks_
 {
     replay = std::fopen(path, "rb");
     if (!replay) { std::fprintf(stderr, "%s: cannot open %s\n", devname.c_str(), path); return false; }
+    lossless = true;
     start(pace_us_, max_blocks_);
     return true;
 }
@@ -152,6 +158,7 @@ void csyntheticsdr::stop()
 {
     do_exit = true;
     cv.notify_all();
+    cv_space.notify_all();
     if (producer.joinable()) producer.join();
     if (replay) { std::fclose(replay); replay = nullptr; }
 }

@@ -126,13 +126,14 @@ protected:
     std::unique_ptr<cbuffer> ring;
     std::thread producer;
     std::mutex mtx;
-    std::condition_variable cv;
+    std::condition_variable cv, cv_space;
     std::atomic<int> newdata{0};
     std::atomic<bool> do_exit{false};
     uint32_t cur_rcnt = 0, produced = 0, overruns = 0;
     bool held = false;          // guarded by mtx: read() handed the oldest ring slot to the engine, consume() has not returned it yet
     int pace_us = 0, max_blocks = 0;
     FILE *replay = nullptr;
+    bool lossless = false;      // replay: a recording has no clock -- the producer waits for a free ring slot instead of dropping a block
     static void asynch_threadf(csyntheticsdr *d);
     // resampler model (ccontrol): accumulated slip in samples while a correction is set
     float correction = 0.0f;

@@ -80,12 +80,15 @@ def test_slots_with_tails_through_the_schedule_equal_the_single_plan(b, synth, G
             if cnt == 0:
                 continue
             self_ptr = send[q].data_ptr() + roots[q].start * slot
-            b.assemble_slots(pk[q].data_ptr() + off[q], pstride, sc[q].data_ptr(), sstride, nrows, B, recv[q].data_ptr(), G, cnt, slot, toff,
-                             self_rank=q, self_ptr=self_ptr)
+            want_scalars = not (G == 4 and T == 6)             # one shape without a scalars block: the read counters still reach the headers
+            b.assemble_slots(pk[q].data_ptr() + off[q], pstride, sc[q].data_ptr() if want_scalars else None, sstride, nrows, B, recv[q].data_ptr(), G, cnt,
+                             slot, toff, self_rank=q, self_ptr=self_ptr)
             torch.cuda.synchronize()
             for j, t in enumerate(roots[q]):
                 got = pk[q][off[q] + j * pstride: off[q] + j * pstride + pbytes].cpu().numpy().view(np.int8)
                 assert np.array_equal(got, exp[t]["packet"]), (half, q, j)
+                if not want_scalars:
+                    continue
                 s = b.parse_scalars(sc[q][j * sstride: (j + 1) * sstride].cpu().numpy(), nrows)
                 for k in ("lag", "mag", "frac", "phasor"):
                     assert np.array_equal(s[k].view(np.uint8), exp[t][k].view(np.uint8)), (half, q, j, k)
