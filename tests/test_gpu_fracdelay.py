@@ -113,11 +113,13 @@ def _residual_delay(y, r, band=0.25):
     return -slope / (2 * np.pi)
 
 
-def test_non_integer_delays_come_out_aligned_with_the_ramp_applied(b, model):
+@pytest.mark.parametrize("L", [1 << 15, 1 << 13, 1 << 12])
+def test_non_integer_delays_come_out_aligned_with_the_ramp_applied(b, model, L):
     # known answer: rows delayed by d + delta samples (delta = +-0.5: the half-sample case, 0.25, -0.4).  The integer lag is
     # whatever the correlation peak says (d or d + 1 for a half-sample delay); the caller supplies the remainder
     # (matlabclient/notes.m:9-40: the parabolic estimate needs a signal-dependent calibration before it can be consumed).
-    L = 1 << 15
+    # L = 2^15: the long blocks' second four-step pass; 2^13 (B = 16384, the reference's block size): the pass on K1's network;
+    # 2^12: the generic LDS kernel -- an answer that does not come from the oracle.
     total = [37.5, -120.5, 300.25, -7.4]
     phis = [0.4, -1.1, 2.5, 0.0]
     rows = _bandlimited_rows(L, total, phis)
