@@ -48,6 +48,9 @@ __device__ __forceinline__ bool wait_word(const unsigned int *word, unsigned int
         v = (unsigned int)__builtin_amdgcn_readfirstlane((int)w);
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");      // what the publisher stored before the word is visible to this wave's loads
+    // the L1 invalidate completes asynchronously: the OTHER waves of the workgroup load behind the barrier this wave joins next, so it
+    // waits the invalidate out first (MI355X_MICROARCH.md, inter-workgroup visibility: poll -> acquire -> vmcnt(0) -> barrier -> loads)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     return true;
 }
 constexpr int kRefWaitBudget = 1 << 20;      // polls of >= 0.3 us: a reference item takes ~10 us, this is a third of a second

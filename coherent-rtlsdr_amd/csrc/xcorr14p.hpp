@@ -203,7 +203,10 @@ __device__ __forceinline__ void xcorr_row14(const XcorrArgs &a, unsigned char *s
     int *refok = reinterpret_cast<int *>(red) + 48;
     if (a.fold && tid < 64) {
         const bool ok = (unsigned int)__builtin_amdgcn_readfirstlane((int)ref_early) == a.refgen;
-        if (ok) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");      // this CU's L1 holds nothing older than the published spectrum
+        if (ok) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");          // this CU's L1 holds nothing older than the published spectrum ...
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // ... once the (asynchronous) invalidate is through: before the barrier below lets the other waves load
+        }
         if (tid == 0) *refok = ok ? 1 : 0;
     }
     __syncthreads();
