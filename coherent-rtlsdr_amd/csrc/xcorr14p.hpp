@@ -362,7 +362,17 @@ __device__ __forceinline__ void xcorr_row14(const XcorrArgs &a, unsigned char *s
 
 
 // ---- K0: reference spectrum, conj, [slot][group] layout ------------------------------------------
+// 16 bytes written THROUGH the XCD's L2 (sc1): what a workgroup of the same launch on another XCD is to read needs no write-back of
+// the whole L2 behind it (MI355X_MICROARCH.md, publish-large: write-through stores + vmcnt(0) + flag against plain stores + release fence)
+__device__ __forceinline__ void store16_sc1(float4 *p, float4 v)
+{
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    const f32x4 x = {v.x, v.y, v.z, v.w};
+    asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(p), "v"(x) : "memory");
+}
 // one block's reference row -> conj(spectrum) in the junction's register order; whole 512-thread workgroup
+// SC1: the spectrum is for rows of this same launch (folded K1): write-through stores
+template <bool SC1 = false>
 __device__ __forceinline__ void ref_spectrum_row14(unsigned char *smem, const int8_t *__restrict__ ref_row, const c2 *__restrict__ twA, const c2 *__restrict__ twB,
                                                    float4 *__restrict__ refspec4, uint32_t xor80)
 {
@@ -389,8 +399,11 @@ __device__ __forceinline__ void ref_spectrum_row14(unsigned char *smem, const in
         }
         dft16p<-1>(u);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) // conj(sfft[0]) for the conjugate multiply of src/ccoherent.cc:177-179
-            refspec4[j * 1024 + g] = make_float4(u[2 * j].x, -u[2 * j].y, u[2 * j + 1].x, -u[2 * j + 1].y);
+        for (int j = 0; j < 8; ++j) { // conj(sfft[0]) for the conjugate multiply of src/ccoherent.cc:177-179
+            const float4 c = make_float4(u[2 * j].x, -u[2 * j].y, u[2 * j + 1].x, -u[2 * j + 1].y);
+            if constexpr (SC1) store16_sc1(refspec4 + j * 1024 + g, c);
+            else refspec4[j * 1024 + g] = c;
+        }
     }
 }
 __global__ __launch_bounds__(THREADS, 2) void k_ref_spectrum14p(const int8_t *__restrict__ rows, size_t block_stride,
@@ -745,11 +758,14 @@ __global__ __launch_bounds__(THREADS, 2) void k_xcorr_lag14p(XcorrArgs a, const 
     const int id = (int)blockIdx.x - nref;
     const int t = id < 0 ? (int)blockIdx.x : id / row_count, x = id < 0 ? -1 : id % row_count;
     if (x < 0) {
-        ref_spectrum_row14(smem, a.rows + (size_t)t * a.block_stride, reinterpret_cast<const c2 *>(twA), reinterpret_cast<const c2 *>(twB),
-                           reinterpret_cast<float4 *>(a.refspec_w) + (size_t)t * (N / 2), a.xor80);
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");       // this wave's spectrum stores are visible device-wide ...
-        __syncthreads();                                          // ... and so are every wave's, before the word says so
-        if (threadIdx.x == 0) __hip_atomic_store(a.refflag + t, a.refgen, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        ref_spectrum_row14<true>(smem, a.rows + (size_t)t * a.block_stride, reinterpret_cast<const c2 *>(twA), reinterpret_cast<const c2 *>(twB),
+                                 reinterpret_cast<float4 *>(a.refspec_w) + (size_t)t * (N / 2), a.xor80);
+        // write-through stores: once every wave's have been acknowledged (vmcnt(0)) and all waves have said so (barrier), the word may
+        // follow (r03 first cut: plain stores + a release fence per wave, i.e. a write-back of the XCD's whole L2 -- the previous
+        // batch's freshly written packet rows -- in front of every reference item's flag)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (threadIdx.x == 0) __hip_atomic_store(a.refflag + t, a.refgen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         return;
     }
     const int row = a.row_begin + x;
