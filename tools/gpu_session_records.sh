@@ -6,6 +6,7 @@ timeout -k 10 900 python -m pytest tests -m gpu -x -q > $O/tests.log 2>&1; echo 
 timeout -k 10 500 bash profiles/run_profile.sh r03 > $O/profile.log 2>&1; echo "profile rc=$?"; tail -5 $O/profile.log
 timeout -k 10 300 python bench.py > $O/r03_bench_default.json 2> $O/default.err; echo "default rc=$?"
 timeout -k 10 200 python bench.py --steps 20 --warmup 5 > $O/r03_bench_driver.json 2> $O/driver.err; echo "driver rc=$?"
+timeout -k 10 200 python bench.py --no-extras --no-cpu-baseline --frac-apply > $O/r03_bench_default_frac.json 2> $O/default_frac.err; echo "default frac rc=$?"
 timeout -k 10 120 python bench.py --steps 20 --warmup 5 --nsig 128 --no-extras --no-cpu-baseline > $O/r03_bench_nsig128.json 2> $O/nsig128.err; echo "nsig128 rc=$?"
 timeout -k 10 120 python bench.py --nsig 128 --no-extras --no-cpu-baseline > $O/r03_bench_nsig128_T64.json 2> $O/nsig128b.err; echo "nsig128 T64 rc=$?"
 timeout -k 10 200 python bench.py --nsig 21 --steps 4096 --warmup 256 --nbuf 128 --no-extras --no-cpu-baseline > $O/r03_bench_cfg2.json 2> $O/cfg2.err; echo "cfg2 rc=$?"
