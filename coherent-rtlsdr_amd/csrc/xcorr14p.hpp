@@ -368,7 +368,10 @@ __device__ __forceinline__ void store16_sc1(float4 *p, float4 v)
 {
     typedef float f32x4 __attribute__((ext_vector_type(4)));
     const f32x4 x = {v.x, v.y, v.z, v.w};
-    asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(p), "v"(x) : "memory");
+    // the s_nop is part of the instruction as far as the compiler is concerned: a store of more than 8 bytes needs a wait state before
+    // a VALU write to the registers that hold its data, hipcc's hazard recognizer pads nothing around inline asm, and whatever it
+    // schedules next may well write them (seen in the two-row kernel: garbage spectra; the packed kernel's schedule happened to be safe)
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" : : "v"(p), "v"(x) : "memory");
 }
 // one block's reference row -> conj(spectrum) in the junction's register order; whole 512-thread workgroup
 // SC1: the spectrum is for rows of this same launch (folded K1): write-through stores
